@@ -1,0 +1,792 @@
+/*
+ * enc_kernels.h -- wave64 pixel / bit kernels of the macroblock pipeline (device code, gfx950).
+ *
+ * Every function is called by ALL 64 lanes of the row's wavefront (see wave.h).  LDS blocks use
+ * stride 16 like the reference's scratch buffers.  "H:n" = /root/reference/src/h264-lab.h:n names
+ * the reference behaviour each kernel reproduces.
+ *
+ * Coefficient blocks keep the reference's storage order index = 4*k_h + k_v and CAVLC scans that
+ * index 15..0 -- the reference has no zig-zag; parity is defined by its bitstream.
+ */
+#ifndef H264E_ENC_KERNELS_H
+#define H264E_ENC_KERNELS_H
+
+#include "wave.h"
+#include "tables.h"
+#include "h264e_dev.h"
+
+#define MV_NA H264E_MV_NA
+#define NNZ_NA 64
+#define AV_T 1
+#define AV_L 2
+#define AV_TL 4
+#define AV_TR 8
+#define QMODE_I4 2
+#define QMODE_INTER 8
+#define QMODE_I16 9
+#define QMODE_CHROMA 5
+#define QD_RND 6
+#define QD_THR1 10
+#define QD_THR2 18
+#define MUL_LAMBDA(x, l) ((x)*(l) >> 4)
+
+DEV int mvx(mv32 v) { return (int16_t)(v & 0xffff); }
+DEV int mvy(mv32 v) { return (int16_t)((uint32_t)v >> 16); }
+DEV mv32 mvmk(int x, int y) { return (mv32)(((uint32_t)y << 16) | ((uint32_t)x & 0xffff)); }
+DEV mv32 mvadd(mv32 a, mv32 b) { return mvmk(mvx(a) + mvx(b), mvy(a) + mvy(b)); }
+DEV mv32 mvsub(mv32 a, mv32 b) { return mvmk(mvx(a) - mvx(b), mvy(a) - mvy(b)); }
+DEV mv32 mvround(mv32 a) { return mvmk((mvx(a) + 1) & ~3, (mvy(a) + 1) & ~3); }     /* H:3498 */
+
+struct qblk_t { int16_t qv[16]; int16_t dq[16]; };
+
+/* ------------------------------------------------------------------ row bit writer */
+
+struct BitW
+{
+    uint64_t acc;       /* pending bits, right aligned */
+    int nacc;           /* < 32 between calls */
+    uint32_t pos;       /* words written */
+    uint32_t cap;       /* capacity in words */
+    int overflow;
+    uint32_t *buf;      /* global memory: MSB-first 32-bit words */
+};
+
+/* H:2688-2702: append n <= 32 bits.  Uniform: all lanes hold the same state and store the same word. */
+DEV void bw_put(BitW &b, int n, uint32_t v)
+{
+    b.acc = (b.acc << n) | (uint64_t)v;
+    b.nacc += n;
+    if (b.nacc >= 32)
+    {
+        b.nacc -= 32;
+        if (b.pos < b.cap) b.buf[b.pos] = (uint32_t)(b.acc >> b.nacc);
+        else b.overflow = 1;
+        b.pos++;
+        b.acc &= (1ull << b.nacc) - 1;
+    }
+}
+DEV int ue_len(uint32_t v) { return 2*(32 - clz32(v + 1)) - 1; }                    /* H:3402 */
+DEV void bw_ue(BitW &b, uint32_t v)                                                 /* H:2738 */
+{
+    int n = ue_len(v);
+    if (n > 32) { bw_put(b, n - 32, 0); n = 32; }
+    bw_put(b, n, v + 1);
+}
+DEV void bw_se(BitW &b, int v) { bw_ue(b, (uint32_t)(v > 0 ? 2*v - 1 : -2*v)); }   /* H:2760 */
+DEV int se_len(int v) { return ue_len((uint32_t)(v > 0 ? 2*v - 1 : -2*v)); }        /* H:3410 */
+DEV uint32_t bw_bits(const BitW &b) { return b.pos*32u + (uint32_t)b.nacc; }
+
+/* ------------------------------------------------------------------ picture access */
+
+struct Plane { const uint8_t *p; int w, h, stride; };
+
+/* four samples (x..x+3, y), little-endian packed, coordinates clamped to the picture: this IS the
+ * reference's border extension (H:2232-2248) without storing the border */
+DEV uint32_t ref_load4(const Plane &P, int x, int y)
+{
+    y = imin(imax(y, 0), P.h - 1);
+    const uint8_t *r = P.p + (size_t)y*P.stride;
+    if (x >= 0 && x + 3 < P.w)
+    {
+        uint32_t v;
+        memcpy(&v, r + x, 4);
+        return v;
+    }
+    uint32_t v = 0;
+    for (int k = 0; k < 4; k++) v |= (uint32_t)r[imin(imax(x + k, 0), P.w - 1)] << (8*k);
+    return v;
+}
+
+DEV uint32_t lds32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+DEV void lds32_store(uint8_t *p, uint32_t v) { memcpy(p, &v, 4); }
+
+/* ------------------------------------------------------------------ SAD (H:2162-2192) */
+
+/* SAD of the w x h block at integer position (x0,y0) of R against LDS block b (stride 16).  4 samples per lane. */
+DEV int wave_sad_ref(const Plane &R, int x0, int y0, const uint8_t *b, int w, int h)
+{
+    const int g = w >> 2, n = g*h;
+    return wave_sum([&](int l) -> int {
+        if (l >= n) return 0;
+        int r = l/g, c = l - r*g;
+        return (int)sad4_u8(ref_load4(R, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
+    });
+}
+
+/* 16x16 SAD with the four 8x8 quadrant sums (H:2178-2187) */
+DEV int wave_sad_ref_q(const Plane &R, int x0, int y0, const uint8_t *b, int sad4[4])
+{
+    wave_sum4([&](int l, int *v) {
+        int r = l >> 2, c = l & 3;
+        v[(r >> 3)*2 + (c >> 1)] = (int)sad4_u8(ref_load4(R, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
+    }, sad4);
+    return sad4[0] + sad4[1] + sad4[2] + sad4[3];
+}
+
+DEV int wave_sad_lds(const uint8_t *a, const uint8_t *b, int w, int h)
+{
+    const int g = w >> 2, n = g*h;
+    return wave_sum([&](int l) -> int {
+        if (l >= n) return 0;
+        int r = l/g, c = l - r*g;
+        return (int)sad4_u8(lds32(a + 16*r + 4*c), lds32(b + 16*r + 4*c), 0);
+    });
+}
+
+DEV int wave_sad_lds_q(const uint8_t *a, const uint8_t *b, int sad4[4])
+{
+    wave_sum4([&](int l, int *v) {
+        int r = l >> 2, c = l & 3;
+        v[(r >> 3)*2 + (c >> 1)] = (int)sad4_u8(lds32(a + 16*r + 4*c), lds32(b + 16*r + 4*c), 0);
+    }, sad4);
+    return sad4[0] + sad4[1] + sad4[2] + sad4[3];
+}
+
+/* ------------------------------------------------------------------ inter prediction */
+
+DEV int tap6(int a, int b, int c, int d, int e, int f) { return a - 5*b + 20*c + 20*d - 5*e + f; }
+
+/*
+ * Standard H.264 quarter-sample luma interpolation (H:2079-2131) of the 4 samples starting at integer
+ * position (x,y), fraction (fx,fy): half samples from the 6-tap filter, quarter samples as rounded
+ * averages of the two nearest integer/half samples.
+ */
+DEV uint32_t interp_luma4(const Plane &R, int x, int y, int fx, int fy)
+{
+    if (!(fx | fy)) return ref_load4(R, x, y);
+    int th[6][4], cb[6][5];
+    const int r0 = fy ? 0 : 2, r1 = fy ? 5 : 2;
+    for (int r = r0; r <= r1; r++)
+    {
+        uint32_t a = ref_load4(R, x - 4, y + r - 2), b = ref_load4(R, x, y + r - 2), c = ref_load4(R, x + 4, y + r - 2);
+        int p[12];
+        for (int k = 0; k < 4; k++)
+        {
+            p[k] = (int)((a >> (8*k)) & 255); p[4 + k] = (int)((b >> (8*k)) & 255); p[8 + k] = (int)((c >> (8*k)) & 255);
+        }
+        for (int i = 0; i < 4; i++) th[r][i] = tap6(p[i + 2], p[i + 3], p[i + 4], p[i + 5], p[i + 6], p[i + 7]);
+        for (int i = 0; i < 5; i++) cb[r][i] = p[4 + i];
+    }
+    uint32_t out = 0;
+    const int pos = fx + 4*fy;
+    for (int i = 0; i < 4; i++)
+    {
+        int v;
+#define HPH(r) clip255((th[r][i] + 16) >> 5)
+#define HPV(d) clip255((tap6(cb[0][i + d], cb[1][i + d], cb[2][i + d], cb[3][i + d], cb[4][i + d], cb[5][i + d]) + 16) >> 5)
+#define HPD()  clip255((tap6(th[0][i], th[1][i], th[2][i], th[3][i], th[4][i], th[5][i]) + 512) >> 10)
+        switch (pos)
+        {
+        case 1:  v = (cb[2][i] + HPH(2) + 1) >> 1; break;
+        case 2:  v = HPH(2); break;
+        case 3:  v = (cb[2][i + 1] + HPH(2) + 1) >> 1; break;
+        case 4:  v = (cb[2][i] + HPV(0) + 1) >> 1; break;
+        case 5:  v = (HPH(2) + HPV(0) + 1) >> 1; break;
+        case 6:  v = (HPH(2) + HPD() + 1) >> 1; break;
+        case 7:  v = (HPH(2) + HPV(1) + 1) >> 1; break;
+        case 8:  v = HPV(0); break;
+        case 9:  v = (HPV(0) + HPD() + 1) >> 1; break;
+        case 10: v = HPD(); break;
+        case 11: v = (HPV(1) + HPD() + 1) >> 1; break;
+        case 12: v = (cb[3][i] + HPV(0) + 1) >> 1; break;
+        case 13: v = (HPH(3) + HPV(0) + 1) >> 1; break;
+        case 14: v = (HPH(3) + HPD() + 1) >> 1; break;
+        default: v = (HPH(3) + HPV(1) + 1) >> 1; break;
+        }
+#undef HPH
+#undef HPV
+#undef HPD
+        out |= (uint32_t)v << (8*i);
+    }
+    return out;
+}
+
+/* H:4905-4910 interpolate_luma: w x h block whose top-left is (bx,by) + mv (absolute quarter-pel) -> LDS dst */
+DEV void wave_interp_luma(const Plane &R, int bx, int by, mv32 mv, int w, int h, uint8_t *dst)
+{
+    const int g = w >> 2, n = g*h, ix = bx + (mvx(mv) >> 2), iy = by + (mvy(mv) >> 2), fx = mvx(mv) & 3, fy = mvy(mv) & 3;
+    WAVE_FOR(l)
+    {
+        if (l < n)
+        {
+            int r = l/g, c = l - r*g;
+            lds32_store(dst + 16*r + 4*c, interp_luma4(R, ix + 4*c, iy + r, fx, fy));
+        }
+    }
+    wave_sync();
+}
+
+/* H:2065-2077 rounded average of two LDS blocks */
+DEV void wave_avg(const uint8_t *a, const uint8_t *b, uint8_t *d, int w, int h)
+{
+    const int g = w >> 2, n = g*h;
+    WAVE_FOR(l)
+    {
+        if (l < n)
+        {
+            int r = l/g, c = l - r*g;
+            uint32_t x = lds32(a + 16*r + 4*c), y = lds32(b + 16*r + 4*c), o = 0;
+            for (int k = 0; k < 4; k++) o |= ((((x >> (8*k)) & 255) + ((y >> (8*k)) & 255) + 1) >> 1) << (8*k);
+            lds32_store(d + 16*r + 4*c, o);
+        }
+    }
+    wave_sync();
+}
+
+DEV void wave_copy_wh(uint8_t *d, const uint8_t *s, int w, int h)
+{
+    const int g = w >> 2, n = g*h;
+    WAVE_FOR(l)
+    {
+        if (l < n)
+        {
+            int r = l/g, c = l - r*g;
+            lds32_store(d + 16*r + 4*c, lds32(s + 16*r + 4*c));
+        }
+    }
+    wave_sync();
+}
+
+/*
+ * H:2133-2160 + H:4915-4947: 1/8-sample bilinear chroma prediction of one partition for both planes.
+ * (cx,cy) = partition position in the chroma plane, mv = LUMA vector (absolute quarter-pel), dst = U at
+ * column 0, V at column 8 (stride 16), already offset to the partition.
+ */
+DEV void wave_interp_chroma(const Plane &RU, const Plane &RV, int cx, int cy, mv32 mv, int w, int h, uint8_t *dst)
+{
+    const int g = w >> 2, n = g*h, dx = mvx(mv) & 7, dy = mvy(mv) & 7;
+    const int ix = cx + (mvx(mv) >> 3), iy = cy + (mvy(mv) >> 3);
+    const int A = (8 - dx)*(8 - dy), B = dx*(8 - dy), C = (8 - dx)*dy, D = dx*dy;
+    WAVE_FOR(l)
+    {
+        int pl = l >= 32, k = l & 31;
+        if (k < n)
+        {
+            const Plane &R = pl ? RV : RU;
+            int r = k/g, c = k - r*g, p0[5], p1[5];
+            uint32_t a = ref_load4(R, ix + 4*c, iy + r), b = ref_load4(R, ix + 4*c + 4, iy + r);
+            uint32_t e = ref_load4(R, ix + 4*c, iy + r + 1), f = ref_load4(R, ix + 4*c + 4, iy + r + 1), o = 0;
+            for (int i = 0; i < 4; i++) { p0[i] = (int)((a >> (8*i)) & 255); p1[i] = (int)((e >> (8*i)) & 255); }
+            p0[4] = (int)(b & 255); p1[4] = (int)(f & 255);
+            for (int i = 0; i < 4; i++)
+            {
+                int v = (dx | dy) ? (A*p0[i] + B*p0[i + 1] + C*p1[i] + D*p1[i + 1] + 32) >> 6 : p0[i];
+                o |= (uint32_t)v << (8*i);
+            }
+            lds32_store(dst + 8*pl + 16*r + 4*c, o);
+        }
+    }
+    wave_sync();
+}
+
+/* ------------------------------------------------------------------ intra prediction */
+
+/* H:1625-1651: mean of the available edges (NULL = unavailable) of n = 1 << lg samples each, 128 when none */
+DEV int dc_pred(const uint8_t *left, const uint8_t *top, int lg)
+{
+    const int n = 1 << lg;
+    int s = 0, sh = lg - 1;
+    if (left) { for (int i = 0; i < n; i++) s += left[i]; sh++; }
+    if (top)  { for (int i = 0; i < n; i++) s += top[i];  sh++; }
+    if (sh < lg) return 128;
+    return (s + (1 << (sh - 1))) >> sh;
+}
+
+/* H:1677-1714: 16x16 luma prediction, mode 0 V / 1 H / 2 DC, into LDS dst */
+DEV void wave_pred16(uint8_t *dst, const uint8_t *left, const uint8_t *top, int mode)
+{
+    const int dc = mode == 2 ? dc_pred(left, top, 4) : 0;
+    WAVE_FOR(l)
+    {
+        int r = l >> 2, c = l & 3;
+        uint32_t v = mode == 0 ? lds32(top + 4*c) : (uint32_t)(mode == 1 ? left[r] : dc)*0x01010101u;
+        lds32_store(dst + 16*r + 4*c, v);
+    }
+    wave_sync();
+}
+
+/* H:1716-1781: 8x8 U | V prediction (stride 16); left/top = 8 U then 8 V; mode in LUMA numbering */
+DEV void wave_pred_chroma(uint8_t *dst, const uint8_t *left, const uint8_t *top, int mode)
+{
+    WAVE_FOR(l)
+    {
+        if (l < 32)
+        {
+            int pl = l >> 4, r = (l >> 1) & 7, c = l & 1;       /* plane, row, 4-sample group = one DC quadrant */
+            const uint8_t *lf = left ? left + 8*pl : 0, *tp = top ? top + 8*pl : 0;
+            uint32_t v;
+            if (mode == 0) v = lds32(tp + 4*c);
+            else if (mode == 1) v = (uint32_t)lf[r]*0x01010101u;
+            else
+            {
+                int q = (r >> 2)*2 + c, dc;
+                if (q == 0) dc = dc_pred(lf, tp, 2);
+                else if (q == 1) dc = tp ? dc_pred(0, tp + 4, 2) : dc_pred(lf, 0, 2);
+                else if (q == 2) dc = lf ? dc_pred(lf + 4, 0, 2) : dc_pred(0, tp, 2);
+                else dc = dc_pred(lf ? lf + 4 : 0, tp ? tp + 4 : 0, 2);
+                v = (uint32_t)dc*0x01010101u;
+            }
+            lds32_store(dst + 8*pl + 16*r + 4*c, v);
+        }
+    }
+    wave_sync();
+}
+
+/*
+ * One row (4 samples) of intra 4x4 prediction mode m (H.264 8.3.1.2; same samples as H:1834-1960).
+ * E(i): edge sample i steps clockwise from the top-left corner (i > 0 top, i < 0 left).
+ */
+DEV uint32_t i4_pred_row(int m, int y, const uint8_t *t, const uint8_t *lf, int tl, int dc)
+{
+    uint32_t o = 0;
+#define E(i) ((i) == 0 ? tl : (i) > 0 ? (int)t[(i) - 1] : (int)lf[-(i) - 1])
+    for (int x = 0; x < 4; x++)
+    {
+        int v, z, k;
+        switch (m)
+        {
+        case 0: v = t[x]; break;
+        case 1: v = lf[y]; break;
+        default:
+        case 2: v = dc; break;
+        case 3: v = (x + y == 6) ? (t[6] + 3*t[7] + 2) >> 2 : (t[x + y] + 2*t[x + y + 1] + t[x + y + 2] + 2) >> 2; break;
+        case 4: z = x - y; v = (E(z - 1) + 2*E(z) + E(z + 1) + 2) >> 2; break;
+        case 5: z = 2*x - y; k = x - (y >> 1);
+            if (z >= 0 && !(z & 1)) v = (E(k) + E(k + 1) + 1) >> 1;
+            else if (z >= 0)        v = (E(k - 1) + 2*E(k) + E(k + 1) + 2) >> 2;
+            else if (z == -1)       v = (E(-1) + 2*E(0) + E(1) + 2) >> 2;
+            else                    v = (E(-y) + 2*E(-(y - 1)) + E(-(y - 2)) + 2) >> 2;
+            break;
+        case 6: z = 2*y - x; k = y - (x >> 1);
+            if (z >= 0 && !(z & 1)) v = (E(-k) + E(-(k + 1)) + 1) >> 1;
+            else if (z >= 0)        v = (E(-(k - 1)) + 2*E(-k) + E(-(k + 1)) + 2) >> 2;
+            else if (z == -1)       v = (E(-1) + 2*E(0) + E(1) + 2) >> 2;
+            else                    v = (E(x) + 2*E(x - 1) + E(x - 2) + 2) >> 2;
+            break;
+        case 7: k = x + (y >> 1);
+            v = (y & 1) ? (t[k] + 2*t[k + 1] + t[k + 2] + 2) >> 2 : (t[k] + t[k + 1] + 1) >> 1; break;
+        case 8: z = x + 2*y; k = y + (x >> 1);
+            if (z > 5)       v = lf[3];
+            else if (z == 5) v = (lf[2] + 3*lf[3] + 2) >> 2;
+            else if (z & 1)  v = (lf[k] + 2*lf[k + 1] + lf[k + 2] + 2) >> 2;
+            else             v = (lf[k] + lf[k + 1] + 1) >> 1;
+            break;
+        }
+        o |= (uint32_t)v << (8*x);
+    }
+#undef E
+    return o;
+}
+
+/*
+ * H:1810-1962 h264e_intra_choose_4x4: all nine modes evaluated at once, lane = (mode slot, row).
+ * Test order DC,V,DDL,VL,H,HU,DDR,HD,VR with a strict "<" keeps the reference's tie-breaks.
+ * in = input block (stride 16), pred = LDS output (stride 16); returns mode | cost << 4.
+ */
+DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_t *top8, const uint8_t *left4, int tl,
+                       int mpred, int penalty, uint32_t *rows /* LDS [9][4] */)
+{
+    const int order[9] = { 2, 0, 3, 7, 1, 8, 4, 6, 5 };
+    uint8_t t[8], lf[4];
+    for (int k = 0; k < 8; k++) t[k] = (avail & AV_T) ? top8[(k > 3 && !(avail & AV_TR)) ? 3 : k] : 0;
+    for (int k = 0; k < 4; k++) lf[k] = left4[k];
+    const int dc = dc_pred((avail & AV_L) ? lf : 0, (avail & AV_T) ? t : 0, 2);
+    int sads[9];
+    WAVE_FOR(l)
+    {
+        int k = l >> 2, y = l & 3;
+        if (k < 9) rows[4*k + y] = i4_pred_row(order[k], y, t, lf, tl, dc);
+    }
+    wave_sync();
+    for (int k = 0; k < 9; k++)
+    {
+        int m = order[k];
+        if ((m == 0 || m == 3 || m == 7) && !(avail & AV_T)) { sads[k] = -1; continue; }
+        if ((m == 1 || m == 8) && !(avail & AV_L)) { sads[k] = -1; continue; }
+        if ((m == 4 || m == 5 || m == 6) && (avail & (AV_T | AV_L | AV_TL)) != (AV_T | AV_L | AV_TL)) { sads[k] = -1; continue; }
+        int s = 0;
+        for (int y = 0; y < 4; y++) s += (int)sad4_u8(lds32(in + 16*y), rows[4*k + y], 0);
+        sads[k] = s + (m != mpred ? penalty : 0);
+    }
+    int best = 0;
+    for (int k = 1; k < 9; k++)
+        if (sads[k] >= 0 && sads[k] < sads[best]) best = k;
+    wave_sync();
+    WAVE_FOR(l)
+    {
+        if (l < 4) lds32_store(pred + 16*l, rows[4*best + l]);
+    }
+    wave_sync();
+    return order[best] + (sads[best] << 4);
+}
+
+/* ------------------------------------------------------------------ transform / quant */
+
+/*
+ * H:2619-2636 h264e_transform_sub_quant_dequant for n x n blocks (n = mode >> 1): forward 4x4 core
+ * transform of (inp - pred) (H:2385-2409), DC pick-off, dead-zone zeroing (H:2512-2534) and
+ * quantization (H:2536-2597).  One lane per coefficient, 64 coefficients per pass.
+ * Returns the non-zero block mask, first block in the highest bit.
+ */
+DEV unsigned wave_xform_quant(const uint8_t *inp, const uint8_t *pred, int mode, qblk_t *q, int16_t *dc, const uint16_t *qdat)
+{
+    const int n = mode >> 1, i0 = mode & 1, nb = n*n;
+    /* forward transform: coefficient (kh,kv) = sum_x sum_y Cf[kh][x]*Cf[kv][y]*r[y][x]; no rounding anywhere, so
+     * the matrix form equals the reference's butterflies (intermediates stay within int16) */
+    for (int pass = 0; pass*64 < nb*16; pass++)
+    {
+        WAVE_FOR(l)
+        {
+            int idx = pass*64 + l, b = idx >> 4, i = idx & 15;
+            if (b < nb)
+            {
+                const int cf[4][4] = { { 1, 1, 1, 1 }, { 2, 1, -1, -2 }, { 1, -1, -1, 1 }, { 1, -2, 2, -1 } };
+                int kh = i >> 2, kv = i & 3, bx = b % n, by = b / n, s = 0;
+                const uint8_t *pi = inp + 64*by + 4*bx, *pp = pred + 64*by + 4*bx;
+                for (int y = 0; y < 4; y++)
+                {
+                    int rs = 0;
+                    for (int x = 0; x < 4; x++) rs += cf[kh][x]*((int)pi[16*y + x] - (int)pp[16*y + x]);
+                    s += cf[kv][y]*rs;
+                }
+                q[b].dq[i] = (int16_t)s;
+            }
+        }
+    }
+    wave_sync();
+    if (i0)
+    {
+        WAVE_FOR(l) { if (l < nb) dc[l] = q[l].dq[0]; }
+    }
+    unsigned zmask = 0;
+    if (mode == QMODE_INTER || mode == QMODE_CHROMA)
+    {
+        /* per-block test against thr1; for inter also the 8x8-group test against thr2 */
+        unsigned big1 = 0, big2 = 0;    /* bit b set: block b has a coefficient outside [-thr, thr] */
+        for (int pass = 0; pass*64 < nb*16; pass++)
+        {
+            uint64_t m1 = wave_ballot([&](int l) -> int {
+                int idx = pass*64 + l, b = idx >> 4, i = idx & 15;
+                if (b >= nb || i < i0) return 0;
+                unsigned thr = qdat[QD_THR1 + (i & 7)];
+                return (unsigned)(q[b].dq[i] + (int)thr) > 2u*thr;
+            });
+            uint64_t m2 = mode == QMODE_INTER ? wave_ballot([&](int l) -> int {
+                int idx = pass*64 + l, b = idx >> 4, i = idx & 15;
+                if (b >= nb || i < i0) return 0;
+                unsigned thr = qdat[QD_THR2 + (i & 7)];
+                return (unsigned)(q[b].dq[i] + (int)thr) > 2u*thr;
+            }) : 0;
+            for (int k = 0; k < 4; k++)
+            {
+                if ((m1 >> (16*k)) & 0xffff) big1 |= 1u << (pass*4 + k);
+                if ((m2 >> (16*k)) & 0xffff) big2 |= 1u << (pass*4 + k);
+            }
+        }
+        zmask = ~big1 & ((1u << nb) - 1);
+        if (mode == QMODE_INTER)
+        {
+            const unsigned grp[4] = { 0x0033, 0x00CC, 0x3300, 0xCC00 };
+            for (int k = 0; k < 4; k++)
+                if ((~zmask & grp[k]) && !(big2 & grp[k])) zmask |= grp[k];
+        }
+    }
+    unsigned nzbits = 0;    /* bit b: block b has a non-zero quantized coefficient */
+    for (int pass = 0; pass*64 < nb*16; pass++)
+    {
+        uint64_t nzm = wave_ballot([&](int l) -> int {
+            int idx = pass*64 + l, b = idx >> 4, i = idx & 15;
+            if (b >= nb) return 0;
+            if (zmask & (1u << b)) { q[b].qv[i] = 0; return 0; }
+            if (i < i0) return 0;
+            int off = ((i & 1) + ((i >> 2) & 1))*2;            /* H:2366 g_idx2quant */
+            int c = q[b].dq[i], rnd = qdat[QD_RND];
+            if (c < 0) rnd = 0xFFFF - rnd;
+            int v = (c*(int)qdat[off] + rnd) >> 16;
+            q[b].qv[i] = (int16_t)v;
+            q[b].dq[i] = (int16_t)(v*(int)qdat[off + 1]);
+            return v != 0;
+        });
+        for (int k = 0; k < 4; k++)
+            if ((nzm >> (16*k)) & 0xffff) nzbits |= 1u << (pass*4 + k);
+    }
+    wave_sync();
+    unsigned mask = 0;
+    for (int b = 0; b < nb; b++) mask = (mask << 1) | ((nzbits >> b) & 1);
+    return mask;
+}
+
+/* H:2269-2301 hadamar4_2d (result transposed, every store truncated to int16); uniform, in place */
+DEV void hadamard4(int16_t *x)
+{
+    int16_t tmp[16];
+    for (int j = 0; j < 4; j++)
+    {
+        int a = x[j], b = x[4 + j], c = x[8 + j], d = x[12 + j];
+        tmp[4*j + 0] = (int16_t)(a + b + c + d); tmp[4*j + 1] = (int16_t)(a + b - c - d);
+        tmp[4*j + 2] = (int16_t)(a - b - c + d); tmp[4*j + 3] = (int16_t)(a - b + c - d);
+    }
+    for (int i = 0; i < 4; i++)
+    {
+        int a = tmp[i], b = tmp[4 + i], c = tmp[8 + i], d = tmp[12 + i];
+        x[i]     = (int16_t)(a + b + c + d); x[4 + i]  = (int16_t)(a + b - c - d);
+        x[8 + i] = (int16_t)(a - b - c + d); x[12 + i] = (int16_t)(a - b + c - d);
+    }
+}
+
+/* H:2344-2353 h264e_quant_luma_dc (uniform; dc and lev live in LDS) */
+DEV void quant_luma_dc(qblk_t *q, int16_t *dc, int16_t *lev, const uint16_t *qdat)
+{
+    int16_t v[16];
+    for (int i = 0; i < 16; i++) v[i] = dc[i];
+    hadamard4(v);
+    const int quant = (int16_t)qdat[0];
+    for (int i = 0; i < 16; i++)
+    {
+        int r = v[i] < 0 ? (1 << 18) - 0x20000 : 0x20000;
+        v[i] = (int16_t)((v[i]*quant + r) >> 18);
+        lev[i] = v[i];
+    }
+    hadamard4(v);
+    const int deq = (int16_t)(qdat[1] >> 2);
+    for (int i = 0; i < 16; i++) q[i].dq[0] = (int16_t)(v[i]*deq);
+    wave_sync();
+}
+
+/* H:2355-2364 h264e_quant_chroma_dc */
+DEV int quant_chroma_dc(qblk_t *q, int16_t *dc, int16_t *lev, const uint16_t *qdat)
+{
+    int v[4];
+    for (int i = 0; i < 4; i++) v[i] = dc[i];
+    const int quant = (int16_t)(qdat[0] << 1), deq = (int16_t)(qdat[1] >> 1);
+    for (int k = 0; k < 2; k++)
+    {
+        int a = v[0], b = v[1], c = v[2], d = v[3];
+        v[0] = (int16_t)(a + b + c + d); v[1] = (int16_t)(a - b + c - d);
+        v[2] = (int16_t)(a + b - c - d); v[3] = (int16_t)(a - b - c + d);
+        if (!k)
+            for (int i = 0; i < 4; i++)
+            {
+                int r = v[i] < 0 ? (1 << 18) - 0xAAAA : 0xAAAA;
+                v[i] = (int16_t)((v[i]*quant + r) >> 18);
+                lev[i] = (int16_t)v[i];
+            }
+    }
+    for (int i = 0; i < 4; i++) q[i].dq[0] = (int16_t)(v[i]*deq);
+    wave_sync();
+    return (v[0] | v[1] | v[2] | v[3]) != 0;
+}
+
+/*
+ * H:2638-2681 h264e_transform_add: out = clip(pred + inverse transform) for blocks whose mask bit (first
+ * block in bit 31) is set, plain copy of pred otherwise.  One lane per sample; the inverse transform keeps
+ * the reference's pass order (horizontal, then vertical) and int16 intermediates (H:2436-2489).
+ * out may be LDS or global memory; pred has stride 16.
+ */
+DEV void wave_recon(uint8_t *out, int os, const uint8_t *pred, const qblk_t *q, int side, uint32_t mask)
+{
+    const int nb = side*side;
+    for (int pass = 0; pass*64 < nb*16; pass++)
+    {
+        WAVE_FOR(l)
+        {
+            int idx = pass*64 + l, b = idx >> 4, i = idx & 15;
+            if (b < nb)
+            {
+                int x = i & 3, y = i >> 2, bx = b % side, by = b / side;
+                int v = pred[64*by + 4*bx + 16*y + x];
+                if ((mask << b) & 0x80000000u)
+                {
+                    const int16_t *c = q[b].dq;
+                    int f[4];
+                    for (int kv = 0; kv < 4; kv++)      /* horizontal pass: sample x of row kv */
+                    {
+                        int d0 = c[kv], d1 = c[kv + 4], d2 = c[kv + 8], d3 = c[kv + 12];
+                        int e0 = d0 + d2, e1 = d0 - d2, e2 = (d1 >> 1) - d3, e3 = d1 + (d3 >> 1);
+                        f[kv] = (int16_t)(x == 0 ? e0 + e3 : x == 1 ? e1 + e2 : x == 2 ? e1 - e2 : e0 - e3);
+                    }
+                    int g0 = f[0] + f[2], g1 = f[0] - f[2], g2 = (f[1] >> 1) - f[3], g3 = f[1] + (f[3] >> 1);
+                    int hh = y == 0 ? g0 + g3 : y == 1 ? g1 + g2 : y == 2 ? g1 - g2 : g0 - g3;
+                    v = clip255((int16_t)((hh + 32) >> 6) + v);
+                }
+                out[(size_t)(4*by + y)*os + 4*bx + x] = (uint8_t)v;
+            }
+        }
+    }
+    wave_sync();
+}
+
+/* ------------------------------------------------------------------ CAVLC (uniform) */
+
+/*
+ * H:2775-2949 h264e_vlc_encode.  coef[first .. first+maxn-1] scanned in decreasing index order;
+ * nctx = left + top nnz context (NNZ_NA = 64 per unavailable side, 17+17 = chroma DC table).
+ * Returns TotalCoeff.
+ */
+DEV int cavlc_block(BitW &b, const int16_t *coef, int first, int maxn, int nctx)
+{
+    int lev[16], pos[16], total = 0, t1 = 0;
+    for (int i = maxn - 1; i >= 0; i--)
+    {
+        int c = coef[first + i];
+        if (c) { lev[total] = c; pos[total] = i; total++; }
+    }
+    while (t1 < 3 && t1 < total && (lev[t1] == 1 || lev[t1] == -1)) t1++;
+    if (nctx <= 34) nctx = (nctx + 1) >> 1;
+    nctx &= 31;
+    const int tab = nctx < 2 ? 0 : nctx < 4 ? 1 : nctx < 8 ? 2 : nctx < 17 ? 3 : 4;
+    bw_put(b, k_coeff_token[tab][total][t1][0], k_coeff_token[tab][total][t1][1]);
+    if (!total) return 0;
+    if (t1)
+    {
+        uint32_t s = 0;
+        for (int i = 0; i < t1; i++) s = (s << 1) | (uint32_t)(lev[i] < 0);
+        bw_put(b, t1, s);
+    }
+    int sl = (total > 10 && t1 < 3) ? 1 : 0;
+    for (int i = t1; i < total; i++)
+    {
+        int a = iabs(lev[i]), code = 2*a - 2 + (lev[i] < 0), prefix, nsuf, suf;
+        if (i == t1 && t1 < 3) code -= 2;
+        if (sl == 0)
+        {
+            if (code < 14)      { prefix = code; nsuf = 0; suf = 0; }
+            else if (code < 30) { prefix = 14; nsuf = 4; suf = code - 14; }
+            else                { prefix = 15; nsuf = 12; suf = code - 30; }
+        } else
+        {
+            prefix = code >> sl;
+            if (prefix < 15) { nsuf = sl; suf = code - (prefix << sl); }
+            else             { prefix = 15; nsuf = 12; suf = code - (15 << sl); }
+        }
+        bw_put(b, prefix + 1 + nsuf, (1u << nsuf) | (uint32_t)suf);
+        if (sl == 0) sl = 1;
+        if (a > (3 << (sl - 1)) && sl < 6) sl++;
+    }
+    if (total < maxn)
+    {
+        int zeros = pos[0] + 1 - total;
+        if (maxn == 4) bw_put(b, k_total_zeros_cdc[total - 1][zeros][0], k_total_zeros_cdc[total - 1][zeros][1]);
+        else           bw_put(b, k_total_zeros[total - 1][zeros][0], k_total_zeros[total - 1][zeros][1]);
+        for (int k = 0; k < total - 1 && zeros > 0; k++)
+        {
+            int run = pos[k] - pos[k + 1] - 1, zl = zeros > 7 ? 7 : zeros;
+            bw_put(b, k_run_before[zl - 1][run][0], k_run_before[zl - 1][run][1]);
+            zeros -= run;
+        }
+    }
+    return total;
+}
+
+/* ------------------------------------------------------------------ deblocking (on LDS tiles) */
+
+/* normal (bS < 4) luma edge sample, H:1251-1300 / H:1396-1447; p points at q0, s = step across the edge */
+DEV void df_luma_normal(uint8_t *p, int s, int alpha, int beta, int tc0)
+{
+    int p2 = p[-3*s], p1 = p[-2*s], p0 = p[-s], q0 = p[0], q1 = p[s], q2 = p[2*s];
+    if (iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)
+    {
+        int ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta, tc = tc0 + ap + aq;
+        int delta = clip3(-tc, tc, (((q0 - p0)*4) + (p1 - q1) + 4) >> 3);
+        if (ap) p[-2*s] = (uint8_t)(p1 + clip3(-tc0, tc0, ((p2 + ((p0 + q0 + 1) >> 1)) >> 1) - p1));
+        if (aq) p[s]    = (uint8_t)(q1 + clip3(-tc0, tc0, ((q2 + ((p0 + q0 + 1) >> 1)) >> 1) - q1));
+        p[-s] = (uint8_t)clip255(p0 + delta);
+        p[0]  = (uint8_t)clip255(q0 - delta);
+    }
+}
+
+/* strong (bS = 4) luma edge sample, H:1302-1394 */
+DEV void df_luma_strong(uint8_t *p, int s, int alpha, int beta)
+{
+    int p3 = p[-4*s], p2 = p[-3*s], p1 = p[-2*s], p0 = p[-s], q0 = p[0], q1 = p[s], q2 = p[2*s], q3 = p[3*s];
+    if (iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)
+    {
+        int small = iabs(p0 - q0) < ((alpha >> 2) + 2);
+        if (small && iabs(p2 - p0) < beta)
+        {
+            p[-s]   = (uint8_t)((p2 + 2*p1 + 2*p0 + 2*q0 + q1 + 4) >> 3);
+            p[-2*s] = (uint8_t)((p2 + p1 + p0 + q0 + 2) >> 2);
+            p[-3*s] = (uint8_t)((2*p3 + 3*p2 + p1 + p0 + q0 + 4) >> 3);
+        } else
+            p[-s] = (uint8_t)((2*p1 + p0 + q1 + 2) >> 2);
+        if (small && iabs(q2 - q0) < beta)
+        {
+            p[0]   = (uint8_t)((q2 + 2*q1 + 2*q0 + 2*p0 + p1 + 4) >> 3);
+            p[s]   = (uint8_t)((q2 + q1 + p0 + q0 + 2) >> 2);
+            p[2*s] = (uint8_t)((2*q3 + 3*q2 + q1 + q0 + p0 + 4) >> 3);
+        } else
+            p[0] = (uint8_t)((2*q1 + q0 + p1 + 2) >> 2);
+    }
+}
+
+/* H:1217-1249 deblock_chroma */
+DEV void df_chroma(uint8_t *p, int s, int alpha, int beta, int tc0, int bs)
+{
+    int p1 = p[-2*s], p0 = p[-s], q0 = p[0], q1 = p[s];
+    if (!bs || iabs(p0 - q0) >= alpha || iabs(p1 - p0) >= beta || iabs(q1 - q0) >= beta) return;
+    if (bs < 4)
+    {
+        int tc = tc0 + 1, delta = clip3(-tc, tc, (((q0 - p0)*4) + (p1 - q1) + 4) >> 3);
+        p[-s] = (uint8_t)clip255(p0 + delta);
+        p[0]  = (uint8_t)clip255(q0 - delta);
+    } else
+    {
+        p[-s] = (uint8_t)((2*p1 + p0 + q1 + 2) >> 2);
+        p[0]  = (uint8_t)((2*q1 + q0 + p1 + 2) >> 2);
+    }
+}
+
+#define YT_STRIDE 24    /* luma tile: rows -4..15, columns -4..15 at (row+4)*24 + col+4 */
+#define CT_STRIDE 12    /* chroma tile: rows -2..7, columns -2..7 at (row+2)*12 + col+2 */
+
+/*
+ * H:5642-5716 mb_deblock + H:1469-1545 on LDS tiles.  bs[4*e + k]: vertical edge e, rows 4k..4k+3;
+ * bs[16 + 4*e + k]: horizontal edge e.  Luma: 16 lanes per edge, the 8 edges in the reference's order;
+ * chroma: lanes 0..7 U, 8..15 V.  An edge whose FIRST strength is 4 is strong-filtered over all 16
+ * samples (H:1517, H:1534).
+ */
+DEV void wave_deblock(uint8_t *yt, uint8_t *ct0, uint8_t *ct1, const uint8_t *bs, int qp, int qp_left, int qp_top)
+{
+    for (int dir = 0; dir < 2; dir++)
+        for (int e = 0; e < 4; e++)
+        {
+            const uint8_t *s = bs + 16*dir + 4*e;
+            if (!(s[0] | s[1] | s[2] | s[3])) continue;
+            int q = e ? qp : dir ? (qp_top + qp + 1) >> 1 : (qp_left + qp + 1) >> 1;
+            int alpha = k_df_alpha[q], beta = k_df_beta[q];
+            if (s[0] != 4 && !alpha) continue;
+            WAVE_FOR(l)
+            {
+                if (l < 16)
+                {
+                    uint8_t *p = dir ? yt + (4 + 4*e)*YT_STRIDE + 4 + l : yt + (4 + l)*YT_STRIDE + 4 + 4*e;
+                    int across = dir ? YT_STRIDE : 1, st = s[l >> 2];
+                    if (s[0] == 4) df_luma_strong(p, across, alpha, beta);
+                    else if (st) df_luma_normal(p, across, alpha, beta, st < 4 ? k_df_tc0[q][st - 1] : beta);
+                }
+            }
+            wave_sync();
+        }
+    const int cq = k_qpc[qp], cql = k_qpc[qp_left], cqt = k_qpc[qp_top];
+    for (int dir = 0; dir < 2; dir++)
+        for (int e = 0; e < 4; e += 2)
+        {
+            const uint8_t *s = bs + 16*dir + 4*e;
+            int q = e ? cq : dir ? (cqt + cq + 1) >> 1 : (cql + cq + 1) >> 1;
+            int alpha = k_df_alpha[q], beta = k_df_beta[q];
+            if (!(s[0] | s[1] | s[2] | s[3]) || !alpha) continue;
+            WAVE_FOR(l)
+            {
+                if (l < 16)
+                {
+                    uint8_t *t = (l & 8) ? ct1 : ct0;
+                    int i = l & 7, st = s[i >> 1];
+                    uint8_t *p = dir ? t + (2 + 2*e)*CT_STRIDE + 2 + i : t + (2 + i)*CT_STRIDE + 2 + 2*e;
+                    df_chroma(p, dir ? CT_STRIDE : 1, alpha, beta, (st && st < 4) ? k_df_tc0[q][st - 1] : 0, st);
+                }
+            }
+            wave_sync();
+        }
+}
+
+#endif

@@ -1,0 +1,768 @@
+/*
+ * enc_mb.h -- the macroblock pipeline in the wave64 model (device code, gfx950): one wavefront encodes one
+ * macroblock row, macroblock after macroblock (row_step), behind the wavefront dependency of the row above.
+ *
+ * Reproduces, decision for decision, mb_encode and everything below it in /root/reference/src/h264-lab.h
+ * ("H:n"): inter_choose_mode (H:5283), me_search_diamond (H:4973), intra_choose_16x16/4x4 (H:4876, H:4723),
+ * mb_write (H:4378), df_strength/mb_deblock (H:5535, H:5642).  Layout is ours: neighbour state of the row
+ * above comes from per-macroblock records in HBM, the left neighbour lives in LDS, bits go to a per-row
+ * buffer that a second kernel splices (skip runs are resolved there).
+ */
+#ifndef H264E_ENC_MB_H
+#define H264E_ENC_MB_H
+
+#include "enc_kernels.h"
+
+struct RowLds
+{
+    /* ---- carried from macroblock to macroblock along the row */
+    mv32 mv_left[4], mv_tl[4];
+    uint8_t nnz_left[8];
+    int8_t i4_left[4];
+    alignas(4) uint8_t pix_left[32];
+    uint8_t pix_tl[4];
+    uint32_t df_nzflag;
+    mv32 df_mv[25];
+    int left_type, left_qp;
+    alignas(4) uint8_t strip_y[16*4];               /* deblocked columns 12..15 of the left macroblock (luma), 6..7 (chroma) */
+    alignas(4) uint8_t strip_c[2][8*2];
+    BitW bw;
+    int skip_run, lead_skips, coded_any;
+
+    /* ---- per macroblock */
+    mv32 mv_top[8];
+    uint8_t nnz_top[8];
+    int8_t i4_top[4];
+    uint32_t df_nz_top;
+    int top_type, top_qp;
+    alignas(4) uint8_t pix_top[36];                 /* 16 Y, 8 U, 8 V of the macroblock above + 4 Y of the one above-right */
+    mv32 mv[16], mvd[16], cand[20], part_mv[4][4], part_mvd[4][4], ctx_save[12];
+    int8_t i4_mode[16];
+    alignas(4) uint8_t bs[32];
+    uint32_t i4rows[36];
+    alignas(16) uint8_t inp[256];
+    alignas(16) uint8_t inp_c[128];
+    alignas(16) uint8_t pred[256];
+    alignas(16) uint8_t pred_c[128];
+    alignas(16) uint8_t skip_pred[256];
+    alignas(16) uint8_t test[256];
+    alignas(16) uint8_t blk[256];
+    alignas(16) uint8_t p00[256];
+    alignas(16) uint8_t p02[256];
+    alignas(16) uint8_t p20[256];
+    alignas(16) uint8_t p22[256];
+    alignas(16) uint8_t tt[256];
+    alignas(16) uint8_t i4rec[17*24];               /* intra 4x4 working picture: row 0 / column 0 = neighbours */
+    alignas(16) uint8_t ytile[20*YT_STRIDE];
+    alignas(16) uint8_t ctile[2][10*CT_STRIDE];
+    alignas(16) qblk_t qy[16];
+    qblk_t qu[4], qv[4];
+    int16_t dcy[16], dcu[4], dcv[4], lev_dcy[16], lev_dcu[4], lev_dcv[4];
+};
+
+struct MbCtx
+{
+    const h264e_geom_t *G;
+    const h264e_frame_task_t *T;
+    Plane ref[3];
+    uint8_t *dec[3];
+    int x, y, num, avail, type, cost, i16_mode, cropped, used_cand;
+    mv32 mv_skip_pred;
+    unsigned nz_mask;
+    int qp;
+};
+
+struct rect_t { int x0, y0, x1, y1; };
+
+DEV int in_rect(mv32 v, const rect_t &r) { return mvy(v) >= r.y0 && mvy(v) <= r.y1 && mvx(v) >= r.x0 && mvx(v) <= r.x1; }
+DEV mv32 clip_rect(mv32 v, const rect_t &r) { return mvmk(imin(imax(mvx(v), r.x0), r.x1), imin(imax(mvy(v), r.y0), r.y1)); }
+DEV mv32 mb_abs(const MbCtx &m, mv32 v) { return mvadd(v, mvmk(m.x*64, m.y*64)); }
+DEV int mv_cost(const MbCtx &m, mv32 v, mv32 pred)                                  /* H:4952 */
+{
+    return MUL_LAMBDA(se_len(mvx(v) - mvx(pred)) + se_len(mvy(v) - mvy(pred)), (int)k_lambda_mv_q4[m.qp]);
+}
+DEV rect_t mv_limit(const MbCtx &m) { rect_t r = { m.G->lim_x0, m.G->lim_y0, m.G->lim_x1, m.G->lim_y1 }; return r; }
+DEV rect_t mv_qlimit(const MbCtx &m) { rect_t r = { m.G->lim_x0 + 16, m.G->lim_y0 + 16, m.G->lim_x1 - 16, m.G->lim_y1 - 16 }; return r; }
+
+/* ------------------------------------------------------------------ MV prediction (uniform) */
+
+DEV int med3(int a, int b, int c) { return imax(imin(imax(a, b), c), imin(a, b)); }
+
+/* H:3696-3715 me_mv_medianpredictor_put, 4x4-block units */
+DEV void mvp_put(RowLds &L, int x, int y, int w, int h, mv32 mv)
+{
+    L.mv_tl[y] = L.mv_top[x + w - 1];
+    for (int i = 1; i < h; i++) L.mv_tl[y + i] = mv;
+    for (int i = 0; i < h; i++) L.mv_left[y + i] = mv;
+    for (int i = 0; i < w; i++) L.mv_top[x + i] = mv;
+}
+
+/* H:3720-3872 me_mv_medianpredictor_get */
+DEV mv32 mvp_get(const RowLds &L, const MbCtx &m, int x, int y, int w, int h)
+{
+    const int flag = m.avail;
+    int type = 1;
+    mv32 a = L.mv_left[y], b = L.mv_top[x], c = L.mv_top[x + w], d = L.mv_tl[y], ret = 0;
+    if (!x)
+    {
+        if (!(flag & AV_L)) a = MV_NA;
+        if (!(flag & AV_TL)) d = MV_NA;
+    }
+    if (!y)
+    {
+        if (!(flag & AV_T))
+        {
+            b = MV_NA;
+            if (x + w < 4) c = MV_NA;
+            if (x > 0) d = MV_NA;
+        }
+        if (!(flag & AV_TL) && !x) d = MV_NA;
+        if (!(flag & AV_TR) && x + w == 4) c = MV_NA;
+    }
+    if (x + w == 4 && (!(flag & AV_TR) || y)) c = d;
+#define OK(v) ((v) != MV_NA)
+    if (OK(a) && !OK(b) && !OK(c)) type = 2;
+    else if (!OK(a) && OK(b) && !OK(c)) type = 3;
+    else if (!OK(a) && !OK(b) && OK(c)) type = 4;
+    if (w == 2 && h == 4)
+    {
+        if (x == 0) { if (OK(a)) type = 2; } else { if (OK(c)) type = 4; }
+    } else if (w == 4 && h == 2)
+    {
+        if (y == 0) { if (OK(b)) type = 3; } else { if (OK(a)) type = 2; }
+    }
+    if (type == 2) { if (OK(a)) ret = a; }
+    else if (type == 3) { if (OK(b)) ret = b; }
+    else if (type == 4) { if (OK(c)) ret = c; }
+    else if (!(OK(b) || OK(c))) { if (OK(a)) ret = a; }
+    else
+    {
+        if (!OK(a)) a = 0;
+        if (!OK(b)) b = 0;
+        if (!OK(c)) c = 0;
+        ret = mvmk(med3(mvx(a), mvx(b), mvx(c)), med3(mvy(a), mvy(b), mvy(c)));
+    }
+#undef OK
+    return ret;
+}
+
+/* ------------------------------------------------------------------ motion search */
+
+/* H:5181-5193 me_mv_set_range */
+DEV void set_range(mv32 &pnt, rect_t &range, const rect_t &limit, int mby_q)
+{
+    rect_t r = limit;
+    r.y0 = (int16_t)imax(r.y0, mby_q - 63*4);
+    r.y1 = (int16_t)imin(r.y1, mby_q + 63*4);
+    pnt = clip_rect(pnt, r);
+    mv32 tl = clip_rect(mvadd(pnt, mvmk(-32*4, -32*4)), r), br = clip_rect(mvadd(pnt, mvmk(32*4, 32*4)), r);
+    range.x0 = mvx(tl); range.y0 = mvy(tl); range.x1 = mvx(br); range.y1 = mvy(br);
+}
+
+/*
+ * H:4973-5176 me_search_diamond for the w x h partition at (px,py) of the macroblock; mv is absolute for
+ * the macroblock (quarter-pel), so the block sits at (px,py) + (mv >> 2) in the reference picture.
+ * The uint16 SAD cache with its 0xffff sentinel is observable behaviour.
+ * L.blk receives the prediction of the returned vector.
+ */
+DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_t &range, mv32 mv_pred, int min_sad, int w, int h)
+{
+    const int dxy[4][2] = { { 4, 0 }, { -4, 0 }, { 0, 4 }, { 0, -4 } };
+    const Plane &R = m.ref[0];
+    const uint8_t *b = L.inp + 16*py + px;
+    uint32_t cache[8];      /* values are uint16 */
+    int dir, cloop, dir_prev, cost;
+    mv32 v;
+    for (;;)
+    {
+        dir = 0; cloop = 4; dir_prev = -1;
+        for (int i = 0; i < 8; i++) cache[i] = 0xffff;
+        do
+        {
+            v = mvadd(mv, mvmk(dxy[dir][0], dxy[dir][1]));
+            if (in_rect(v, range) && cache[dir] == 0xffffu)
+            {
+                cost = wave_sad_ref(R, px + (mvx(v) >> 2), py + (mvy(v) >> 2), b, w, h) + mv_cost(m, v, mv_pred);
+                cache[dir] = (uint32_t)cost & 0xffff;
+                if (cost < min_sad)
+                {
+                    uint32_t corner = 0xffff;
+                    if (dir_prev >= 0) corner = cache[4 + dir];
+                    for (int i = 0; i < 4; i++) { cache[4 + i] = cache[i]; cache[i] = 0xffff; }
+                    if (dir_prev >= 0) cache[dir_prev ^ 1] = corner;
+                    cache[dir ^ 1] = (uint32_t)min_sad & 0xffff;
+                    dir_prev = dir;
+                    dir--;
+                    cloop = 4 + 1;
+                    mv = v;
+                    min_sad = cost;
+                }
+            }
+            dir = (dir + 1) & 3;
+        } while (--cloop);
+
+        int pri = cache[3] >= cache[2] ? 2 : 3, sec = cache[1] >= cache[0] ? 0 : 1;
+        v = mvadd(mv, mvmk(dxy[pri][0] + dxy[sec][0], dxy[pri][1] + dxy[sec][1]));
+        if (in_rect(v, range))
+        {
+            cost = wave_sad_ref(R, px + (mvx(v) >> 2), py + (mvy(v) >> 2), b, w, h) + mv_cost(m, v, mv_pred);
+            if (cost < min_sad)
+            {
+                mv = v;
+                min_sad = cost;
+                continue;       /* H:5074 goto restart */
+            }
+        }
+        break;
+    }
+
+    wave_interp_luma(R, px, py, mv, w, h, L.blk);
+    if (m.T->speed < 9 && in_rect(mv, mv_qlimit(m)))
+    {
+        mv32 vbest = mv, pq = mvmk(0, -1), sq = mvmk(-1, 0);
+        uint32_t ms1 = cache[1], ms2 = cache[3];
+        wave_copy_wh(L.p00, L.blk, w, h);
+        if (cache[3] >= cache[2]) { pq = mvmk(0, 1); ms2 = cache[2]; }
+        if (cache[1] >= cache[0]) { sq = mvmk(1, 0); ms1 = cache[0]; }
+        if (ms2 > ms1) { mv32 s = sq; sq = pq; pq = s; }
+        const mv32 vd = mvadd(pq, sq);
+        for (int i = 0; i < 7; i++)
+        {
+            const uint8_t *cand;
+            switch (i)
+            {
+            case 0: v = mvadd(mv, mvadd(pq, pq)); wave_interp_luma(R, px, py, v, w, h, L.p02); cand = L.p02; break;
+            case 1: v = mvadd(mv, pq); wave_avg(L.p00, L.p02, L.tt, w, h); cand = L.tt; break;
+            case 2: v = mvadd(mv, mvadd(sq, sq)); wave_interp_luma(R, px, py, v, w, h, L.p20); cand = L.p20; break;
+            case 3: v = mvadd(mv, sq); wave_avg(L.p00, L.p20, L.tt, w, h); cand = L.tt; break;
+            case 4: v = mvadd(mv, vd); wave_avg(L.p02, L.p20, L.tt, w, h); cand = L.tt; break;
+            case 5: v = mvadd(mv, mvadd(vd, vd)); wave_interp_luma(R, px, py, v, w, h, L.p22); cand = L.p22; break;
+            default: v = mvadd(mv, mvadd(pq, vd)); wave_avg(L.p22, L.p02, L.tt, w, h); cand = L.tt; break;
+            }
+            cost = wave_sad_lds(cand, b, w, h) + mv_cost(m, v, mv_pred);
+            if (cost < min_sad)
+            {
+                min_sad = cost;
+                vbest = v;
+                wave_copy_wh(L.blk, cand, w, h);
+            }
+        }
+        mv = vbest;
+    }
+    return min_sad;
+}
+
+/* H:5224-5257 mb_inter_partition */
+DEV void partition_hints(const int sad[4], int mode[4])
+{
+    int sum = sad[0] + sad[1] + sad[2] + sad[3];
+    int slope = iabs((sad[0] - sad[2]) + (sad[1] - sad[3])) - iabs((sad[0] - sad[1]) + (sad[2] - sad[3]));
+    int skew = iabs(sad[3] - sad[0]) - iabs(sad[2] - sad[1]);
+    if (slope > (sum >> 4)) mode[1] = 1;
+    if (slope < -(sum >> 4)) mode[2] = 1;
+    if (iabs(skew) > (sum >> 4) && iabs(slope) <= (sum >> 4)) mode[3] = 1;
+}
+
+/* H:4915-4947 interpolate_chroma: every partition of the current type, both planes -> L.pred_c */
+DEV void predict_chroma_inter(RowLds &L, const MbCtx &m)
+{
+    int w = (m.type & 2) ? 4 : 8, h = (m.type & 1) ? 4 : 8, part = 0, x = 0, y = 0;
+    if (m.type == -1) w = h = 8;
+    for (;; part++)
+    {
+        wave_interp_chroma(m.ref[1], m.ref[2], x, y, mb_abs(m, L.mv[part]), w, h, L.pred_c + 16*y + x);
+        x = (x + w) & 7;
+        if (!x)
+        {
+            y = (y + h) & 7;
+            if (!y) break;
+        }
+    }
+}
+
+/*
+ * Chroma half of the early-skip test, H:5322-5349.  For cropped edge macroblocks the reference copies
+ * the padded 8x8 input into mb_pix_store (H:5333), which at that point is the buffer holding the chroma
+ * prediction (ptest after the swap of H:5316): rows 0..3 of the prediction are overwritten by the input
+ * copy before the SAD is taken -- first by U, then again by V.  Reproduced arithmetically:
+ * row r < 4 of plane c is compared with input row 2r + c instead of the prediction.
+ */
+DEV int skip_chroma_ok(const RowLds &L, const MbCtx &m)
+{
+    const int thr = k_skip_thr_inter[m.qp];
+    for (int c = 0; c < 2; c++)
+    {
+        int sad = wave_sum([&](int l) -> int {
+            if (l >= 16) return 0;
+            int r = l >> 1, g = l & 1;
+            uint32_t a = lds32(L.inp_c + 16*r + 8*c + 4*g);
+            uint32_t p = (m.cropped && r < 4) ? lds32(L.inp_c + 16*(2*r + c) + 8*c + 4*g) : lds32(L.pred_c + 16*r + 8*c + 4*g);
+            return (int)sad4_u8(a, p, 0);
+        });
+        if (sad >= thr) return 0;
+    }
+    return 1;
+}
+
+/* H:5283-5524 inter_choose_mode */
+DEV void inter_choose(RowLds &L, MbCtx &m)
+{
+    const int nbits[4] = { 1, 4, 4, 12 };
+    int prefer[4] = { 1, 0, 0, 0 };
+    const Plane &R = m.ref[0];
+    const int bx = m.x*16, by = m.y*16;
+    int sad, sad_skip = 0x7FFFFFFF, sad_best = 0x7FFFFFFF, cand_cost_best = 0, j = 0, ncand = 0, sad4[4];
+    mv32 mv_best = MV_NA;
+
+    /* H:3877-3890 skip predictor */
+    const mv32 mv_pred16 = mvp_get(L, m, 0, 0, 4, 4);
+    m.mv_skip_pred = 0;
+    if (!(~m.avail & (AV_L | AV_T)) && L.mv_left[0] != 0 && L.mv_top[0] != 0) m.mv_skip_pred = mv_pred16;
+    const mv32 mv_skip = m.mv_skip_pred, mv_skip_a = mb_abs(m, mv_skip);
+
+    for (int i = 0; i < 4; i++)
+    {
+        L.df_mv[4 + 5*i] = L.mv_left[i];
+        L.df_mv[i] = L.mv_top[i];
+    }
+
+    if (in_rect(mv_skip_a, mv_qlimit(m)))
+    {
+        wave_interp_luma(R, 0, 0, mv_skip_a, 16, 16, L.skip_pred);
+        sad_skip = wave_sad_lds_q(L.inp, L.skip_pred, sad4);
+        if (imax(imax(sad4[0], sad4[1]), imax(sad4[2], sad4[3])) < (int)k_skip_thr_inter[m.qp])
+        {
+            m.type = -1;
+            L.mv[0] = mv_skip;
+            m.cost = 0;
+            predict_chroma_inter(L, m);
+            if (skip_chroma_ok(L, m))
+            {
+                wave_copy_wh(L.pred, L.skip_pred, 16, 16);
+                return;
+            }
+        }
+        if (m.T->speed < 1) partition_hints(sad4, prefer);
+        mv_best = L.cand[ncand++] = mvround(mv_skip);
+        if (!((mvx(mv_skip) | mvy(mv_skip)) & 3))
+        {
+            sad_best = sad_skip;
+            cand_cost_best = mv_cost(m, mv_skip, mv_pred16);
+            j = 1;
+        }
+    }
+
+    m.used_cand = 1;
+    L.cand[ncand++] = mv_pred16;
+    L.cand[ncand++] = 0;                                                    /* H:3895-3914 */
+    if ((m.avail & AV_L) && L.mv_left[0] != MV_NA) L.cand[ncand++] = L.mv_left[0];
+    if ((m.avail & AV_T) && L.mv_top[0] != MV_NA) L.cand[ncand++] = L.mv_top[0];
+    if ((m.avail & AV_TR) && L.mv_top[4] != MV_NA) L.cand[ncand++] = L.mv_top[4];
+    if (m.x <= 0) L.cand[ncand++] = mvmk(8*4, 0);
+    if (m.y <= 0) L.cand[ncand++] = mvmk(0, 8*4);
+    {
+        const mv32 *clu = m.T->clusters_per_mb ? m.T->clusters_per_mb + 2*m.num : m.T->clusters;
+        L.cand[ncand++] = clu[0];
+        L.cand[ncand++] = clu[1];
+    }
+    {   /* H:5198-5218 round to full-pel, drop duplicates */
+        int k = 1;
+        L.cand[0] = mvround(L.cand[0]);
+        for (int n = 1; n < ncand; n++)
+        {
+            mv32 v = mvround(L.cand[n]);
+            int i;
+            for (i = 0; i < k; i++) if (L.cand[i] == v) break;
+            if (i == k) L.cand[k++] = v;
+        }
+        ncand = k;
+    }
+    wave_sync();
+
+    const rect_t lim = mv_limit(m);
+    for (; j < ncand; j++)
+    {
+        const mv32 cj = L.cand[j], va = mb_abs(m, cj);
+        if (in_rect(va, lim))
+        {
+            int c = mv_cost(m, cj, mv_pred16), s4[4];
+            sad = wave_sad_ref_q(R, bx + (mvx(cj) >> 2), by + (mvy(cj) >> 2), L.inp, s4);
+            if (m.T->speed < 1) partition_hints(s4, prefer);
+            if (sad + c < sad_best + cand_cost_best)
+            {
+                cand_cost_best = c;
+                sad_best = sad;
+                mv_best = cj;
+            }
+        }
+    }
+    sad_best += mv_cost(m, mv_best, mv_pred16);
+
+    /* H:3646-3671: every partitioning is tried from the same predictor state */
+    for (int i = 0; i < 4; i++) { L.ctx_save[i] = L.mv_left[i]; L.ctx_save[4 + i] = L.mv_tl[i]; L.ctx_save[8 + i] = L.mv_top[i]; }
+    m.cost = 0xffffff;
+    int best_n = 0;
+    for (int t = 0; t < 4; t++)
+    {
+        int imv = 0, part_sad = MUL_LAMBDA(nbits[t], (int)k_lambda_q4[m.qp]);
+        const int w = (t & 2) ? 8 : 16, h = (t & 1) ? 8 : 16;
+        int px = 0, py = 0;
+        if (!prefer[t]) continue;
+        for (;;)
+        {
+            rect_t range;
+            mv32 mvabs = mb_abs(m, mv_best);
+            set_range(mvabs, range, lim, m.y*64 + py*4);
+            const mv32 mvp = mvp_get(L, m, px >> 2, py >> 2, w >> 2, h >> 2);
+            if (t)
+            {
+                mvabs = mvround(mb_abs(m, mvp));
+                set_range(mvabs, range, lim, m.y*64 + py*4);
+                sad_best = wave_sad_ref(R, px + (mvx(mvabs) >> 2), py + (mvy(mvabs) >> 2), L.inp + 16*py + px, w, h)
+                         + mv_cost(m, mvabs, mb_abs(m, mvp));
+            }
+            part_sad += diamond(L, m, px, py, mvabs, range, mb_abs(m, mvp), sad_best, w, h);
+            wave_copy_wh(L.test + 16*py + px, L.blk, w, h);
+            const mv32 mv = mvsub(mvabs, mvmk(m.x*64, m.y*64));
+            L.part_mvd[t][imv] = mvsub(mv, mvp);
+            L.part_mv[t][imv++] = mv;
+            mvp_put(L, px >> 2, py >> 2, w >> 2, h >> 2, mv);
+            wave_sync();
+            px = (px + w) & 15;
+            if (!px)
+            {
+                py = (py + h) & 15;
+                if (!py) break;
+            }
+        }
+        for (int i = 0; i < 4; i++) { L.mv_left[i] = L.ctx_save[i]; L.mv_tl[i] = L.ctx_save[4 + i]; L.mv_top[i] = L.ctx_save[8 + i]; }
+        wave_sync();
+        if (part_sad < m.cost)
+        {
+            wave_copy_wh(L.pred, L.test, 16, 16);
+            m.cost = part_sad;
+            m.type = t;
+            best_n = imv;
+        }
+    }
+    for (int i = 0; i < best_n; i++) { L.mv[i] = L.part_mv[m.type][i]; L.mvd[i] = L.part_mvd[m.type][i]; }
+    wave_sync();
+
+    if (m.cost > sad_skip)
+    {
+        m.type = 0;
+        m.cost = sad_skip + mv_cost(m, mv_skip, mv_pred16);
+        L.mv[0] = mv_skip;
+        L.mvd[0] = mvsub(mv_skip, mv_pred16);
+        wave_copy_wh(L.pred, L.skip_pred, 16, 16);
+    }
+}
+
+/* ------------------------------------------------------------------ intra decisions */
+
+/* H:4838-4858 intra_estimate_16x16 + H:4876-4896 intra_choose_16x16 */
+DEV void intra16_choose(RowLds &L, MbCtx &m, const uint8_t *left, const uint8_t *top)
+{
+    const uint8_t valid[8] = { 4, 5, 6, 7, 4, 5, 6, 15 };
+    const uint8_t *p = L.inp;
+    const int v = valid[m.avail & 7];
+    int mode, sad4[4];
+    int dx = iabs(p[0] - p[15]) + iabs(p[15*16] - p[15*16 + 15]) + iabs(p[8*16] - p[8*16 + 15]);
+    int dy = iabs(p[0] - p[15*16]) + iabs(p[15] - p[15*16 + 15]) + iabs(p[8] - p[15*16 + 8]);
+    if (dx > 30 + 3*dy && dy < (100 + 50 - m.qp) && (v & 1)) mode = 0;
+    else if (dy > 30 + 3*dx && dx < (100 + 50 - m.qp) && (v & 2)) mode = 1;
+    else mode = 2;
+    m.i16_mode = mode;
+    wave_pred16(L.test, left, top, mode);
+    int sad = wave_sad_lds_q(L.inp, L.test, sad4) + MUL_LAMBDA(ue_len((uint32_t)mode + 1), (int)k_lambda_q4[m.qp]) + (int)k_lambda_i16_q4[m.qp];
+    if (sad < m.cost)
+    {
+        m.cost = sad;
+        m.type = 6;
+        wave_copy_wh(L.pred, L.test, 16, 16);
+    }
+}
+
+/* H:4723-4833 intra_choose_4x4: 16 blocks in raster order, each predicted from reconstructed neighbours */
+DEV void intra4_choose(RowLds &L, MbCtx &m)
+{
+    const uint8_t block2avail[16] = { 0x07, 0x23, 0x23, 0x2b, 0x9b, 0x77, 0xff, 0x77, 0x9b, 0xff, 0xff, 0x77, 0x9b, 0x77, 0xff, 0x77 };
+    uint8_t *r0 = L.i4rec + 24 + 4;       /* sample (0,0); row stride 24, 4 spare columns on the left keep rows 4-byte aligned */
+    const int avail = m.avail;
+    int cost = k_lambda_i4_q4[m.qp];
+    unsigned nz_mask = 0;
+    WAVE_FOR(l)
+    {
+        if (l < 16) { r0[-24 + l] = L.pix_top[l]; r0[24*l - 1] = L.pix_left[l]; }
+        else if (l < 20) r0[-24 + l] = L.pix_top[32 + l - 16];
+        else if (l == 20) r0[-24 - 1] = L.pix_tl[0];
+    }
+    wave_sync();
+    for (int n = 0; n < 16; n++)
+    {
+        const int r = n >> 2, c = n & 3;
+        uint8_t *blk = r0 + 24*4*r + 4*c;
+        const uint8_t *bin = L.inp + (c + r*16)*4;
+        uint8_t *pr = L.tt;                                     /* prediction / reconstruction of this block, stride 16 */
+        int a = (avail & block2avail[n]) | (block2avail[n] >> 4);
+        if (!(block2avail[n] & AV_TL))
+            if ((n <= 3 && (avail & AV_T)) || (n > 3 && (avail & AV_L))) a |= AV_TL;
+        if (n < 3 && (avail & AV_T)) a |= AV_TR;
+        int mpred = imin(L.i4_left[r], L.i4_top[c]);
+        if (mpred < 0) mpred = 2;
+        uint8_t left4[4];
+        for (int i = 0; i < 4; i++) left4[i] = blk[24*i - 1];
+        int res = wave_i4_choose(bin, pr, a, blk - 24, left4, blk[-24 - 1], mpred, MUL_LAMBDA(3, (int)k_lambda_q4[m.qp]), L.i4rows);
+        const int mode = res & 15, sad = res >> 4;
+        L.i4_left[r] = L.i4_top[c] = (int8_t)mode;
+        L.i4_mode[n] = (int8_t)(mode == mpred ? -1 : mode > mpred ? mode - 1 : mode);
+        unsigned coded = 0;
+        if (sad > (int)k_skip_thr_i4x4[m.qp])
+        {
+            coded = wave_xform_quant(bin, pr, QMODE_I4, L.qy + n, (int16_t *)0, m.T->qdat[0]);
+            if (coded) wave_recon(pr, 16, pr, L.qy + n, 1, 0x80000000u);
+        } else
+        {
+            WAVE_FOR(l) { if (l < 16) { L.qy[n].qv[l] = 0; L.qy[n].dq[l] = 0; } }
+            wave_sync();
+        }
+        nz_mask = (nz_mask << 1) | coded;
+        cost += sad;
+        WAVE_FOR(l) { if (l < 4) lds32_store(blk + 24*l, lds32(pr + 16*l)); }
+        wave_sync();
+    }
+    m.nz_mask = nz_mask & 0xffff;
+    if (cost < m.cost)
+    {
+        m.cost = cost;
+        m.type = 5;
+    }
+}
+
+/* ------------------------------------------------------------------ macroblock write */
+
+/* H:4378-4715 mb_write.  Reconstruction goes to the LDS deblock tiles; bits to the row buffer. */
+DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
+{
+    const uint8_t scan8[16] = { 0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15 };         /* H:920 */
+    const int i16 = m.type >= 6;
+    int cbpl = 0, cbpc = 0, cbp = 0;
+    uint8_t nz[9];
+    uint8_t *ty = L.ytile + 4*YT_STRIDE + 4;
+    uint8_t *tc[2] = { L.ctile[0] + 2*CT_STRIDE + 2, L.ctile[1] + 2*CT_STRIDE + 2 };
+
+    if (m.type != 5)
+        for (int i = 0; i < 4; i++) L.i4_left[i] = L.i4_top[i] = 2;
+
+    L.df_nzflag = ((L.df_nzflag >> 4) & 0x84210) | L.df_nz_top;
+    for (int i = 0; i < 4; i++)
+    {
+        nz[5 + i] = L.nnz_top[i];
+        nz[3 - i] = L.nnz_left[i];
+    }
+    nz[4] = 0;
+    wave_sync();
+    for (int i = 0; i < 4; i++) L.nnz_top[i] = L.nnz_left[i] = 0;
+
+    if (m.type != -1)
+    {
+        if (m.type != 5)
+        {
+            unsigned mask = wave_xform_quant(L.inp, L.pred, i16 ? QMODE_I16 : QMODE_INTER, L.qy, L.dcy, m.T->qdat[0]);
+            m.nz_mask = mask & 0xffff;
+            if (i16)
+            {
+                quant_luma_dc(L.qy, L.dcy, L.lev_dcy, m.T->qdat[0]);
+                mask = 0xFFFF;
+            }
+            wave_recon(ty, YT_STRIDE, L.pred, L.qy, 4, mask << 16);
+        } else
+        {
+            WAVE_FOR(l)
+            {
+                int r = l >> 2, c = l & 3;
+                lds32_store(ty + YT_STRIDE*r + 4*c, lds32(L.i4rec + 24 + 4 + 24*r + 4*c));
+            }
+            wave_sync();
+        }
+        if (m.nz_mask & 0xCC00) cbpl |= 1;
+        if (m.nz_mask & 0x3300) cbpl |= 2;
+        if (m.nz_mask & 0x00CC) cbpl |= 4;
+        if (m.nz_mask & 0x0033) cbpl |= 8;
+
+        for (int c = 0; c < 2; c++)
+        {
+            qblk_t *q = c ? L.qv : L.qu;
+            int16_t *dc = c ? L.dcv : L.dcu;
+            unsigned mask = wave_xform_quant(L.inp_c + 8*c, L.pred_c + 8*c, QMODE_CHROMA, q, dc, m.T->qdat[1]);
+            if (mask) cbpc = 2;
+            const int dc_flag = quant_chroma_dc(q, dc, c ? L.lev_dcv : L.lev_dcu, m.T->qdat[1]);
+            cbpc |= dc_flag;
+            if (dc_flag)
+            {
+                const unsigned am = mask;
+                WAVE_FOR(l)
+                {
+                    int blk4 = l >> 4, i = l & 15;
+                    if (i && (~am & (8u >> blk4))) q[blk4].dq[i] = 0;
+                }
+                wave_sync();
+                mask = 15;
+            }
+            wave_recon(tc[c], CT_STRIDE, L.pred_c + 8*c, q, 2, mask << 28);
+        }
+        cbpc = imin(cbpc, 2);
+        /* roll back to skip (H:4493-4499) */
+        if (!(m.type | cbpl | cbpc) && L.mv[0] == m.mv_skip_pred) m.type = -1;
+    }
+
+    if (m.type == -1)
+    {
+        L.skip_run++;
+        for (int i = 4; i < 8; i++) L.nnz_top[i] = L.nnz_left[i] = 0;
+        mvp_put(L, 0, 0, 4, 4, L.mv[0]);
+        for (int i = 0; i < 16; i++) L.df_mv[5 + 5*(i >> 2) + (i & 3)] = L.mv[0];
+        WAVE_FOR(l)
+        {
+            int r = l >> 2, c = l & 3;
+            lds32_store(ty + YT_STRIDE*r + 4*c, lds32(L.pred + 16*r + 4*c));
+            if (l < 32)
+            {
+                int pl = l >> 4, rr = (l >> 1) & 7, g = l & 1;
+                lds32_store(tc[pl] + CT_STRIDE*rr + 4*g, lds32(L.pred_c + 16*rr + 8*pl + 4*g));
+            }
+        }
+        wave_sync();
+    } else
+    {
+        int mb_type = m.type;
+        if (i16)
+        {
+            if (cbpl) cbpl = 15;
+            mb_type += m.i16_mode + cbpc*4 + (cbpl ? 12 : 0);
+        }
+        if (mb_type >= 5 && m.T->slice_type == 2) mb_type -= 5;
+        if (m.T->slice_type != 2)
+        {
+            if (L.coded_any) bw_ue(b, (uint32_t)L.skip_run);
+            else L.lead_skips = L.skip_run;             /* the splice kernel writes this run: it may extend into earlier rows */
+            L.skip_run = 0;
+        }
+        L.coded_any = 1;
+        bw_ue(b, (uint32_t)mb_type);
+        if (m.type == 3) bw_put(b, 4, 15);              /* four sub_mb_type ue(0) */
+        if (m.type >= 5)
+        {
+            if (m.type == 5)
+                for (int i = 0; i < 16; i++)
+                {
+                    int md = L.i4_mode[scan8[i]];
+                    if (md < 0) bw_put(b, 1, 1); else bw_put(b, 4, (uint32_t)md);
+                }
+            int cm = m.i16_mode;
+            if (!(cm & 1)) cm ^= 2;
+            bw_ue(b, (uint32_t)cm);
+            mvp_put(L, 0, 0, 4, 4, MV_NA);
+        } else
+        {
+            const int dx = (m.type & 2) ? 2 : 4, dyb = (m.type & 1) ? 2 : 4;
+            int x = 0, y = 0;
+            for (int part = 0;; part++)
+            {
+                bw_se(b, mvx(L.mvd[part]));
+                bw_se(b, mvy(L.mvd[part]));
+                mvp_put(L, x, y, dx, dyb, L.mv[part]);
+                for (int yy = 0; yy < dyb; yy++)
+                    for (int xx = 0; xx < dx; xx++) L.df_mv[5 + 5*(y + yy) + x + xx] = L.mv[part];
+                x = (x + dx) & 3;
+                if (!x)
+                {
+                    y = (y + dyb) & 3;
+                    if (!y) break;
+                }
+            }
+        }
+        cbp = cbpl + (cbpc << 4);
+        if (!i16) bw_ue(b, k_cbp2code[m.type < 5][cbp]);
+        if (cbp || i16) bw_se(b, 0);                    /* mb_qp_delta: QP is constant within a frame (no MB-level rate control) */
+        if (i16) nz[4] = (uint8_t)cavlc_block(b, L.lev_dcy, 0, 16, nz[3] + nz[5]);
+        if (cbpl)
+        {
+            for (int i = 0; i < 16; i++)
+            {
+                const int j = scan8[i], k = 4 + (j & 3) - (j >> 2);
+                if (cbp & (1 << (i >> 2)))
+                {
+                    nz[k] = (uint8_t)cavlc_block(b, L.qy[j].qv, i16, 16 - i16, nz[k - 1] + nz[k + 1]);
+                    if (nz[k]) L.df_nzflag |= 1u << (5 + (j & 3) + 5*(j >> 2));
+                } else
+                    nz[k] = 0;
+            }
+            for (int i = 0; i < 4; i++)
+            {
+                L.nnz_top[i] = nz[1 + i];
+                L.nnz_left[i] = nz[7 - i];
+            }
+        }
+        if (cbpc)
+        {
+            cavlc_block(b, L.lev_dcu, 0, 4, 17 + 17);
+            cavlc_block(b, L.lev_dcv, 0, 4, 17 + 17);
+            if (cbpc > 1)
+                for (int c = 0; c < 2; c++)
+                {
+                    uint8_t nzc[5];
+                    const int off = c ? 6 : 4;
+                    const qblk_t *q = c ? L.qv : L.qu;
+                    nzc[2] = 0;
+                    for (int i = 0; i < 2; i++)
+                    {
+                        nzc[3 + i] = L.nnz_top[off + i];
+                        nzc[1 - i] = L.nnz_left[off + i];
+                    }
+                    for (int i = 0; i < 4; i++)
+                    {
+                        const int k = 2 + (i & 1) - (i >> 1);
+                        nzc[k] = (uint8_t)cavlc_block(b, q[i].qv, 1, 15, nzc[k - 1] + nzc[k + 1]);
+                    }
+                    for (int i = 0; i < 2; i++)
+                    {
+                        L.nnz_top[off + i] = nzc[1 + i];
+                        L.nnz_left[off + i] = nzc[3 - i];
+                    }
+                }
+        }
+        if (cbpc != 2)
+            for (int i = 4; i < 8; i++) L.nnz_top[i] = L.nnz_left[i] = 0;
+    }
+    wave_sync();
+}
+
+/* ------------------------------------------------------------------ deblock strengths */
+
+/* H:5535-5637 df_strength + edge masking of H:5653-5661 -> L.bs */
+DEV void df_strength(RowLds &L, const MbCtx &m, int top_type)
+{
+    uint32_t flag = L.df_nzflag;
+    if (m.type < 5)
+    {
+        int k = 0;
+        for (int y = 0; y < 4; y++, flag >>= 1, k++)
+            for (int x = 0; x < 4; x++, flag >>= 1, k++)
+            {
+                const mv32 a = L.df_mv[k + 4], c = L.df_mv[k + 5], t = L.df_mv[k];
+                L.bs[4*x + y] = (uint8_t)((flag & (3 << 4)) ? 2 : (iabs(mvx(a) - mvx(c)) > 3 || iabs(mvy(a) - mvy(c)) > 3) ? 1 : 0);
+                L.bs[16 + 4*y + x] = (uint8_t)((flag & 33) ? 2 : (iabs(mvx(t) - mvx(c)) > 3 || iabs(mvy(t) - mvy(c)) > 3) ? 1 : 0);
+            }
+    } else
+    {
+        for (int i = 0; i < 16; i++) L.bs[i] = L.bs[16 + i] = (uint8_t)(i < 4 ? 0 : 3);
+    }
+    if (m.type >= 5 || (m.x && L.left_type >= 5)) for (int i = 0; i < 4; i++) L.bs[i] = 4;
+    if (m.type >= 5 || top_type >= 5) for (int i = 0; i < 4; i++) L.bs[16 + i] = 4;
+    if (!m.x) for (int i = 0; i < 4; i++) L.bs[i] = 0;
+    if (!m.y) for (int i = 0; i < 4; i++) L.bs[16 + i] = 0;
+    wave_sync();
+}
+
+#endif

@@ -1,0 +1,389 @@
+/*
+ * enc_row.h -- row driver (row_begin / row_step / row_end) and the slice splice (finalize_frame), wave64 model.
+ *
+ * row_step = the reference's mb_encode (h264-lab.h:5724-5812) for macroblock (x, row): neighbour records of
+ * the row above come from HBM (written by that row's wavefront), the left neighbour is in LDS.
+ * finalize_frame = the tail of encode_slice (h264-lab.h:6451-6456): concatenates the row bit buffers behind
+ * the slice header, resolves mb_skip_run across rows, adds the RBSP trailing bits, and evaluates the
+ * mv_clusters speculation.
+ */
+#ifndef H264E_ENC_ROW_H
+#define H264E_ENC_ROW_H
+
+#include "enc_mb.h"
+
+DEV void row_begin(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, const h264e_frame_task_t &T, int row)
+{
+    WAVE_FOR(l)
+    {
+        if (l < 4) { L.mv_left[l] = 0; L.mv_tl[l] = 0; L.i4_left[l] = -1; L.pix_tl[l] = 0; }
+        if (l < 8) L.nnz_left[l] = NNZ_NA;
+        if (l < 32) L.pix_left[l] = 0;
+        if (l < 25) L.df_mv[l] = 0;
+        L.strip_y[l] = 0;
+        if (l < 32) L.strip_c[l >> 4][l & 15] = 0;
+    }
+    L.df_nzflag = 0;
+    L.left_type = 0;
+    L.left_qp = T.qp;
+    L.bw.acc = 0; L.bw.nacc = 0; L.bw.pos = 0; L.bw.overflow = 0;
+    L.bw.cap = (uint32_t)G.row_words;
+    L.bw.buf = C.rowbits + (size_t)row*G.row_words;
+    L.skip_run = 0; L.lead_skips = 0; L.coded_any = 0;
+    wave_sync();
+}
+
+/* neighbour record of the macroblock above -> LDS (h264-lab.h:742-745 contexts, :590-606 deblock state) */
+DEV void load_top(RowLds &L, const h264e_geom_t &G, const h264e_mbbottom_t *above, int x, int have_top)
+{
+    WAVE_FOR(l)
+    {
+        if (have_top)
+        {
+            const h264e_mbbottom_t &B = above[x];
+            if (l < 8) L.pix_top[4*l + 0] = B.pix[4*l + 0], L.pix_top[4*l + 1] = B.pix[4*l + 1], L.pix_top[4*l + 2] = B.pix[4*l + 2], L.pix_top[4*l + 3] = B.pix[4*l + 3];
+            else if (l < 12) L.mv_top[l - 8] = B.mv[l - 8];
+            else if (l < 20) L.nnz_top[l - 12] = B.nnz[l - 12];
+            else if (l < 24) L.i4_top[l - 20] = B.i4[l - 20];
+            else if (l == 24) { L.df_nz_top = B.df_nz; L.top_type = B.type; L.top_qp = B.qp; }
+            else if (l < 29)
+            {
+                int k = l - 25;
+                L.pix_top[32 + k] = x + 1 < G.nmbx ? above[x + 1].pix[k] : 0;
+            } else if (l == 29) L.mv_top[4] = x + 1 < G.nmbx ? above[x + 1].mv[0] : 0;
+        } else
+        {
+            if (l < 36) L.pix_top[l] = 0;
+            if (l < 5) L.mv_top[l] = 0;
+            if (l < 8) L.nnz_top[l] = NNZ_NA;
+            if (l < 4) L.i4_top[l] = -1;
+            if (l == 0) { L.df_nz_top = 0; L.top_type = 0; L.top_qp = 0; }
+        }
+    }
+    wave_sync();
+}
+
+/* h264-lab.h:5731-5740 + 3536-3562: input macroblock -> LDS, replicating the last valid column / row of cropped pictures */
+DEV void load_input(RowLds &L, const h264e_geom_t &G, const h264e_frame_task_t &T, int mbx, int mby)
+{
+    WAVE_FOR(l)
+    {
+        {
+            int r = l >> 2, c = l & 3, yy = imin(mby*16 + r, G.height - 1);
+            const uint8_t *p = T.in[0] + (size_t)yy*T.in_stride[0];
+            uint32_t v = 0;
+            for (int k = 0; k < 4; k++) v |= (uint32_t)p[imin(mbx*16 + 4*c + k, G.width - 1)] << (8*k);
+            lds32_store(L.inp + 16*r + 4*c, v);
+        }
+        if (l < 32)
+        {
+            int pl = l >> 4, r = (l >> 1) & 7, c = l & 1, yy = imin(mby*8 + r, G.height/2 - 1);
+            const uint8_t *p = T.in[1 + pl] + (size_t)yy*T.in_stride[1 + pl];
+            uint32_t v = 0;
+            for (int k = 0; k < 4; k++) v |= (uint32_t)p[imin(mbx*8 + 4*c + k, G.width/2 - 1)] << (8*k);
+            lds32_store(L.inp_c + 16*r + 8*pl + 4*c, v);
+        }
+    }
+    wave_sync();
+}
+
+DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, const h264e_frame_task_t &T, int row, int x)
+{
+    MbCtx m;
+    m.G = &G; m.T = &T;
+    for (int c = 0; c < 3; c++)
+    {
+        m.ref[c].p = C.rec[T.ref_sel][c];
+        m.ref[c].w = G.W >> (c ? 1 : 0); m.ref[c].h = G.H >> (c ? 1 : 0); m.ref[c].stride = m.ref[c].w;
+        m.dec[c] = C.rec[T.ref_sel ^ 1][c];
+    }
+    m.x = x; m.y = row; m.num = row*G.nmbx + x;
+    m.avail = (row > 0 ? AV_T : 0) | (row > 0 && x != G.nmbx - 1 ? AV_TR : 0) | (x > 0 ? AV_L : 0) | (row > 0 && x > 0 ? AV_TL : 0);
+    m.cropped = G.cropping && ((x + 1)*16 > G.width || (row + 1)*16 > G.height);
+    m.type = 0; m.cost = 0x7FFFFFFF; m.i16_mode = 0; m.used_cand = 0; m.mv_skip_pred = 0; m.nz_mask = 0;
+    m.qp = T.qp;
+
+    h264e_mbbottom_t *rowrec = C.bottom + (size_t)row*G.nmbx;
+    load_top(L, G, rowrec - G.nmbx, x, row > 0);
+    load_input(L, G, T, x, row);
+
+    const uint8_t *left = (m.avail & AV_L) ? L.pix_left : (const uint8_t *)0;
+    const uint8_t *top = (m.avail & AV_T) ? L.pix_top : (const uint8_t *)0;
+    BitW bw = L.bw;
+
+    if (T.slice_type == 0) inter_choose(L, m);
+    if (m.type >= 0)
+    {
+        intra16_choose(L, m, left, top);
+        if (T.speed < 2 || T.slice_type != 0) intra4_choose(L, m);
+    }
+    if (m.type >= 5) wave_pred_chroma(L.pred_c, left ? left + 16 : (const uint8_t *)0, top ? top + 16 : (const uint8_t *)0, m.i16_mode);
+    else predict_chroma_inter(L, m);
+
+    mb_write(L, m, bw);
+    L.bw = bw;
+
+    /* record for the mv_clusters validation (h264-lab.h:5776-5779 updates them with mv[0] of every non-intra MB) */
+    {
+        h264e_mbrec_t *rec = C.mbrec + (size_t)T.frame_slot*G.nmb + m.num;
+        rec->mv0 = m.type < 5 ? L.mv[0] : 0;
+        rec->type = (int8_t)m.type;
+        rec->used_cand = (uint8_t)m.used_cand;
+    }
+
+    /* keep the UNFILTERED right column / bottom row for intra prediction (h264-lab.h:4693-4714) */
+    uint8_t *ty = L.ytile + 4*YT_STRIDE + 4;
+    uint8_t *tc0 = L.ctile[0] + 2*CT_STRIDE + 2, *tc1 = L.ctile[1] + 2*CT_STRIDE + 2;
+    h264e_mbbottom_t &B = rowrec[x];
+    WAVE_FOR(l)
+    {
+        if (l < 16)
+        {
+            L.pix_left[l] = ty[YT_STRIDE*l + 15];
+            B.pix[l] = ty[YT_STRIDE*15 + l];
+        } else if (l < 32)
+        {
+            int pl = (l >> 3) & 1, i = l & 7;
+            const uint8_t *t = pl ? tc1 : tc0;
+            L.pix_left[16 + 8*pl + i] = t[CT_STRIDE*i + 7];
+            B.pix[16 + 8*pl + i] = t[CT_STRIDE*7 + i];
+        } else if (l < 35)
+        {
+            int c = l - 32;
+            L.pix_tl[c] = L.pix_top[c == 0 ? 15 : 15 + 8*c];
+        }
+    }
+    wave_sync();
+
+    /* deblock on the LDS tiles: left strips from LDS (previous macroblock), top strips from HBM (row above) */
+    const int W = G.W, Wc = G.W >> 1;
+    uint8_t *dy = m.dec[0] + (size_t)(row*16)*W + x*16;
+    uint8_t *du = m.dec[1] + (size_t)(row*8)*Wc + x*8, *dv = m.dec[2] + (size_t)(row*8)*Wc + x*8;
+    if (!T.no_deblock)
+    {
+        df_strength(L, m, L.top_type);
+        WAVE_FOR(l)
+        {
+            if (l < 16) lds32_store(L.ytile + (4 + l)*YT_STRIDE, lds32(L.strip_y + 4*l));
+            else if (l < 32)
+            {
+                int pl = (l >> 3) & 1, i = l & 7;
+                uint8_t *t = L.ctile[pl] + (2 + i)*CT_STRIDE;
+                t[0] = L.strip_c[pl][2*i]; t[1] = L.strip_c[pl][2*i + 1];
+            } else if (l < 48)
+            {
+                int r = (l - 32) >> 2, c = l & 3;
+                uint32_t v = 0;
+                if (row > 0) memcpy(&v, dy - (size_t)(4 - r)*W + 4*c, 4);
+                lds32_store(L.ytile + r*YT_STRIDE + 4 + 4*c, v);
+            } else if (l < 56)
+            {
+                int pl = (l >> 2) & 1, r = (l >> 1) & 1, c = l & 1;
+                const uint8_t *s = (pl ? dv : du) - (size_t)(2 - r)*Wc + 4*c;
+                uint8_t *t = L.ctile[pl] + r*CT_STRIDE + 2 + 4*c;
+                for (int k = 0; k < 4; k++) t[k] = row > 0 ? s[k] : 0;
+            }
+        }
+        wave_sync();
+        wave_deblock(L.ytile, L.ctile[0], L.ctile[1], L.bs, T.qp, L.left_qp, L.top_qp);
+    }
+    /* write the macroblock and the neighbour samples the filter changed (3 luma / 1 chroma sample deep) */
+    WAVE_FOR(l)
+    {
+        int r = l >> 2, c = l & 3;
+        uint32_t v = lds32(ty + YT_STRIDE*r + 4*c);
+        memcpy(dy + (size_t)r*W + 4*c, &v, 4);
+        if (l < 32)
+        {
+            int pl = l >> 4, rr = (l >> 1) & 7, g = l & 1;
+            uint32_t u = lds32((pl ? tc1 : tc0) + CT_STRIDE*rr + 4*g);
+            memcpy((pl ? dv : du) + (size_t)rr*Wc + 4*g, &u, 4);
+        }
+    }
+    if (!T.no_deblock)
+    {
+        WAVE_FOR(l)
+        {
+            if (l < 16)
+            {
+                if (x > 0) { uint32_t v = lds32(L.ytile + (4 + l)*YT_STRIDE); memcpy(dy + (size_t)l*W - 4, &v, 4); }
+            } else if (l < 28)
+            {
+                int r = 1 + (l - 16)/4, c = l & 3;                          /* rows -3..-1 of the tile = rows 1..3 */
+                if (row > 0) { uint32_t v = lds32(L.ytile + r*YT_STRIDE + 4 + 4*c); memcpy(dy - (size_t)(4 - r)*W + 4*c, &v, 4); }
+            } else if (l < 44)
+            {
+                int pl = (l - 28) >> 3, i = (l - 28) & 7;
+                if (x > 0) (pl ? dv : du)[(size_t)i*Wc - 1] = L.ctile[pl][(2 + i)*CT_STRIDE + 1];
+            } else if (l < 48)
+            {
+                int pl = (l - 44) >> 1, c = l & 1;
+                if (row > 0) { uint32_t v; memcpy(&v, L.ctile[pl] + CT_STRIDE + 2 + 4*c, 4); memcpy((pl ? dv : du) - Wc + 4*c, &v, 4); }
+            }
+        }
+    }
+    /* carried deblock state: deblocked right columns of this macroblock */
+    WAVE_FOR(l)
+    {
+        if (l < 16) lds32_store(L.strip_y + 4*l, lds32(ty + YT_STRIDE*l + 12));
+        else if (l < 32)
+        {
+            int pl = (l >> 3) & 1, i = l & 7;
+            const uint8_t *t = (pl ? tc1 : tc0) + CT_STRIDE*i + 6;
+            L.strip_c[pl][2*i] = t[0]; L.strip_c[pl][2*i + 1] = t[1];
+        } else if (l < 36) B.mv[l - 32] = L.mv_top[l - 32];
+        else if (l < 44) B.nnz[l - 36] = L.nnz_top[l - 36];
+        else if (l < 48) B.i4[l - 44] = L.i4_top[l - 44];
+        else if (l == 48)
+        {
+            B.df_nz = (uint8_t)(L.df_nzflag >> 20);
+            B.type = (int8_t)m.type;
+            B.qp = (uint8_t)T.qp;
+            B.pad = 0;
+        }
+    }
+    L.left_type = m.type;
+    L.left_qp = T.qp;
+    wave_sync();
+}
+
+DEV void row_end(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, int row)
+{
+    BitW bw = L.bw;
+    const uint32_t nbits = bw_bits(bw);
+    if (bw.nacc)
+    {
+        const int pad = 32 - bw.nacc;
+        bw_put(bw, pad, 0);
+    }
+    h264e_rowmeta_t &M = C.rowmeta[row];
+    M.nbits = nbits;
+    M.lead_skips = L.coded_any ? L.lead_skips : G.nmbx;
+    M.trail_skips = L.coded_any ? L.skip_run : 0;
+    M.overflow = bw.overflow;
+    wave_sync();
+}
+
+/* ------------------------------------------------------------------ slice splice (one wavefront per chain) */
+
+struct SpliceState { uint32_t *out; uint32_t wpos; uint32_t carry; int cbits; uint32_t cap_words; int overflow; };
+
+/* append nbits (<= 64) right-aligned bits */
+DEV void splice_put(SpliceState &s, int nbits, uint64_t v)
+{
+    while (nbits > 0)
+    {
+        int take = imin(nbits, 32 - s.cbits);
+        uint32_t part = (uint32_t)((v >> (nbits - take)) & ((take == 32) ? 0xffffffffu : ((1u << take) - 1)));
+        s.carry = (take == 32) ? part : ((s.carry << take) | part);
+        s.cbits += take;
+        nbits -= take;
+        if (s.cbits == 32)
+        {
+            if (s.wpos < s.cap_words) s.out[s.wpos] = bswap32(s.carry); else s.overflow = 1;
+            s.wpos++;
+            s.carry = 0; s.cbits = 0;
+        }
+    }
+}
+
+/* append the first nbits of an MSB-first word buffer, 64 words per pass */
+DEV void splice_words(SpliceState &s, const uint32_t *w, uint32_t nbits)
+{
+    const uint32_t nfull = nbits >> 5;
+    const int cb = s.cbits;
+    const uint32_t carry = s.carry;
+    for (uint32_t base = 0; base < nfull; base += 64)
+    {
+        WAVE_FOR(l)
+        {
+            uint32_t k = base + (uint32_t)l;
+            if (k < nfull)
+            {
+                uint32_t prev = k ? w[k - 1] : carry, cur = w[k];
+                uint32_t o = cb ? ((prev << (32 - cb)) | (cur >> cb)) : cur;
+                if (s.wpos + k < s.cap_words) s.out[s.wpos + k] = bswap32(o);
+            }
+        }
+    }
+    if (s.wpos + nfull > s.cap_words) s.overflow = 1;
+    if (nfull)
+    {
+        s.wpos += nfull;
+        s.carry = cb ? (w[nfull - 1] & ((1u << cb) - 1)) : 0;
+    }
+    const int rem = (int)(nbits & 31);
+    if (rem) splice_put(s, rem, (uint64_t)(w[nfull] >> (32 - rem)));
+}
+
+DEV void put_ue64(SpliceState &s, uint32_t v)
+{
+    int n = 2*(32 - clz32(v + 1)) - 1;
+    splice_put(s, n, (uint64_t)v + 1);
+}
+
+DEV void clusters_step(mv32 c[2], mv32 mv)                                  /* h264-lab.h:5263-5278 */
+{
+    int n = mvx(mv)*mvx(mv) + mvy(mv)*mvy(mv);
+    int n0 = mvx(c[0])*mvx(c[0]) + mvy(c[0])*mvy(c[0]), n1 = mvx(c[1])*mvx(c[1]) + mvy(c[1])*mvy(c[1]);
+    if (n < n1) c[0] = mvmk((63*mvx(c[0]) + mvx(mv) + 32) >> 6, (63*mvy(c[0]) + mvy(mv) + 32) >> 6);
+    if (n >= n0) c[1] = mvmk((63*mvx(c[1]) + mvx(mv) + 32) >> 6, (63*mvy(c[1]) + mvy(mv) + 32) >> 6);
+}
+
+DEV void finalize_frame(const h264e_geom_t &G, const h264e_chain_dev_t &C, const h264e_frame_task_t &T)
+{
+    SpliceState s;
+    const uint32_t start = (*C.cursor + 3u) & ~3u;
+    s.out = (uint32_t *)(C.arena + start);
+    s.wpos = 0; s.carry = 0; s.cbits = 0; s.overflow = 0;
+    s.cap_words = (C.arena_cap - start) >> 2;
+    splice_put(s, T.hdr_nbits, T.hdr_bits);
+    int run = 0, overflow = 0;
+    for (int row = 0; row < G.nmby; row++)
+    {
+        const h264e_rowmeta_t &M = C.rowmeta[row];
+        overflow |= M.overflow;
+        run += M.lead_skips;
+        if (M.lead_skips < G.nmbx || M.nbits)
+        {
+            if (T.slice_type != 2) put_ue64(s, (uint32_t)run);
+            wave_sync();
+            splice_words(s, C.rowbits + (size_t)row*G.row_words, M.nbits);
+            wave_sync();
+            run = M.trail_skips;
+        }
+    }
+    const int all_skipped = run == G.nmb;
+    if (run) put_ue64(s, (uint32_t)run);                                    /* h264-lab.h:6451-6454 */
+    splice_put(s, 1, 1);                                                    /* rbsp_stop_one_bit, h264-lab.h:3999 */
+    uint32_t nbytes = s.wpos*4 + (uint32_t)((s.cbits + 7) >> 3);
+    if (s.cbits) { int pad = 32 - s.cbits; splice_put(s, pad, 0); }
+
+    /* mv_clusters speculation check: is the speculated state a fixed point of every update of this frame? */
+    const h264e_mbrec_t *rec = C.mbrec + (size_t)T.frame_slot*G.nmb;
+    int moved = 0;
+    if (!T.clusters_per_mb)
+    {
+        for (int base = 0; base < G.nmb; base += 64)
+        {
+            uint64_t bad = wave_ballot([&](int l) -> int {
+                int k = base + l;
+                if (k >= G.nmb || rec[k].type >= 5) return 0;
+                mv32 c[2] = { T.clusters[0], T.clusters[1] };
+                clusters_step(c, rec[k].mv0);
+                return c[0] != T.clusters[0] || c[1] != T.clusters[1];
+            });
+            if (bad) moved = 1;
+        }
+    }
+    h264e_frameout_t &F = C.fout[T.frame_slot];
+    F.offset = start;
+    F.nbytes = nbytes;
+    F.all_skipped = all_skipped;
+    F.clusters_moved = moved;
+    F.overflow = overflow | s.overflow;
+    *C.cursor = start + ((nbytes + 3u) & ~3u);
+    wave_sync();
+}
+
+#endif

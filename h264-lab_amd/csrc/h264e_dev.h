@@ -1,0 +1,102 @@
+/*
+ * h264e_dev.h -- data layout shared by the kernels and their launcher.
+ *
+ * HBM layout per CHAIN (one chain = one sequential stream of frames; GOPs are independent chains):
+ *   rec[2][3]   two reconstructed pictures (ping-pong reference / current), coded size, no guard band:
+ *               out-of-picture reference reads clamp coordinates, which equals the reference's
+ *               replicated borders (h264-lab.h:2232-2248, 3580-3596)
+ *   bottom      one 64-byte record per macroblock: what the row below needs from it
+ *   progress    one counter per macroblock row: macroblocks finished in that row (wavefront hand-off)
+ *   rowbits     one bit buffer per macroblock row (MSB-first 32-bit words)
+ *   mbrec       per macroblock {mv[0], type, used-candidates} for the mv_clusters validation
+ *   arena       finished slice RBSPs, appended by the finalize kernel
+ */
+#ifndef H264E_DEV_H
+#define H264E_DEV_H
+#include <stdint.h>
+
+#define H264E_MV_NA 0x8000
+#define H264E_ROW_BYTES_PER_MB 2048     /* capacity of a row bit buffer, per macroblock of the row */
+
+typedef int32_t mv32;                   /* packed (y << 16) | (x & 0xffff), quarter-pel */
+
+typedef struct
+{
+    int width, height;                  /* picture size */
+    int W, H;                           /* coded size (multiples of 16) */
+    int nmbx, nmby, nmb, cropping;
+    int lim_x0, lim_y0, lim_x1, lim_y1; /* mv_limit, h264-lab.h:6322-6324 */
+    int row_words;                      /* 32-bit words per row bit buffer */
+} h264e_geom_t;
+
+typedef struct
+{
+    uint8_t pix[32];                    /* UNFILTERED bottom line: 16 Y, 8 U, 8 V (intra prediction of the row below) */
+    mv32 mv[4];                         /* bottom row of 4x4 motion vectors, H264E_MV_NA for intra */
+    uint8_t nnz[8];                     /* CAVLC contexts: 4 Y, 2 U, 2 V */
+    int8_t i4[4];                       /* intra 4x4 modes of the bottom blocks */
+    uint8_t df_nz;                      /* coded-coefficient flags of the bottom 4x4 blocks (deblock strength) */
+    int8_t type;
+    uint8_t qp;
+    uint8_t pad;
+} h264e_mbbottom_t;
+
+typedef struct
+{
+    uint32_t nbits;                     /* bits in the row buffer */
+    int32_t lead_skips;                 /* skipped macroblocks before the first coded one (== nmbx when none is coded) */
+    int32_t trail_skips;                /* skipped macroblocks after the last coded one */
+    int32_t overflow;
+} h264e_rowmeta_t;
+
+typedef struct
+{
+    mv32 mv0;
+    int8_t type;
+    uint8_t used_cand;                  /* the macroblock consumed the mv_clusters start candidates */
+    uint8_t pad[2];
+} h264e_mbrec_t;
+
+typedef struct
+{
+    uint32_t offset;                    /* byte offset of the RBSP in the chain's arena */
+    uint32_t nbytes;
+    int32_t all_skipped;
+    int32_t clusters_moved;             /* some macroblock's update would change the speculated mv_clusters state */
+    int32_t overflow;
+    int32_t pad[3];
+} h264e_frameout_t;
+
+typedef struct
+{
+    uint8_t *rec[2][3];
+    h264e_mbbottom_t *bottom;
+    int *progress;
+    uint32_t *rowbits;
+    h264e_rowmeta_t *rowmeta;
+    h264e_mbrec_t *mbrec;               /* [frame slots][nmb] */
+    uint8_t *arena;
+    uint32_t arena_cap;
+    uint32_t *cursor;
+    h264e_frameout_t *fout;             /* [frame slots] */
+} h264e_chain_dev_t;
+
+typedef struct
+{
+    const uint8_t *in[3];
+    int in_stride[3];
+    int active;
+    int slice_type;                     /* 0 = P, 2 = I */
+    int qp;
+    int speed;
+    int no_deblock;
+    int ref_sel;                        /* rec[ref_sel] is the reference, rec[ref_sel ^ 1] the picture being built */
+    int frame_slot;
+    int hdr_nbits;                      /* NAL header byte + slice header, MSB-aligned at bit hdr_nbits-1 */
+    uint64_t hdr_bits;
+    mv32 clusters[2];                   /* speculated mv_clusters state for every macroblock of the frame ... */
+    const mv32 *clusters_per_mb;        /* ... or, when not NULL, an exact per-macroblock trajectory [nmb][2] */
+    uint16_t qdat[2][42];               /* quantizer tables (h264-lab.h:5839-5912), built by the host */
+} h264e_frame_task_t;
+
+#endif

@@ -1,0 +1,856 @@
+/*
+ * h264e_host.c -- C host side of the MI355X encoder: the reference's public API (include/h264e_mi355x.h)
+ * over the HIP C ABI (include/h264e_hip.h).
+ *
+ * What stays on the host, as in the reference: frame-type / GOP bookkeeping (h264-lab.h:6725-6811), SPS / PPS /
+ * slice header syntax (h264-lab.h:4040-4333), NAL framing with emulation prevention (h264-lab.h:3926-4022),
+ * frame-level rate control (h264-lab.h:5924-6141) and the quantizer tables (h264-lab.h:5839-5912).
+ * What runs on the GPU: the whole macroblock loop (encode_slice -> mb_encode) and the slice splice.
+ *
+ * mv_clusters (h264-lab.h:766) is the one raster-serial state the GPU cannot carry: macroblocks are encoded
+ * with a SPECULATED value and the host validates it afterwards: exact trajectory from the
+ * per-macroblock records, comparison of the rounded start candidates actually consumed, re-encode of the frame
+ * with the exact per-macroblock values when they differ.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "../../include/h264e_mi355x.h"
+#include "../../include/h264e_hip.h"
+
+#define MAGIC 0x4D493335u   /* "MI35" */
+#define SLICE_P 0
+#define SLICE_I 2
+
+static int g_device = -1;
+static char g_host_err[256];
+
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+const char *H264E_last_error(void) { return g_host_err[0] ? g_host_err : h264e_hip_last_error(); }
+void H264E_set_device(int device) { g_device = device; }
+
+static int pick_device(void)
+{
+    const char *e;
+    if (g_device >= 0) return g_device;
+    e = getenv("H264E_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+/* ------------------------------------------------------------------ tables needed on the host */
+
+/* per-QP rounding / dead-zone constants of the reference (h264-lab.h:993-1030, 1083-1094) */
+static const uint16_t k_rnd_inter[52] = {
+    11665, 11665, 11665, 11665, 11665, 11665, 11665, 11665, 11665, 11665, 11665, 12868, 14071, 15273, 16476, 17679, 17740, 17801,
+    17863, 17924, 17985, 17445, 16904, 16364, 15823, 15283, 15198, 15113, 15027, 14942, 14857, 15667, 16478, 17288, 18099, 18909,
+    19213, 19517, 19822, 20126, 20430, 16344, 12259, 8173, 4088, 4088, 4088, 4088, 4088, 4088, 4088, 4088 };
+static const uint16_t k_thr_inter[52] = {
+    31878, 31878, 31878, 31878, 31878, 31878, 31878, 31878, 31878, 31878, 31878, 33578, 35278, 36978, 38678, 40378, 41471, 42563,
+    43656, 44748, 45841, 46432, 47024, 47615, 48207, 48798, 49354, 49911, 50467, 51024, 51580, 51580, 51580, 51580, 51580, 51580,
+    52222, 52864, 53506, 54148, 54790, 45955, 37120, 28286, 19451, 10616, 9326, 8036, 6745, 5455, 4165, 4165 };
+static const uint16_t k_thr_inter2[52] = {
+    45352, 45352, 45352, 45352, 45352, 45352, 45352, 45352, 45352, 45352, 45352, 41100, 36848, 32597, 28345, 24093, 25904, 27715,
+    29525, 31336, 33147, 33429, 33711, 33994, 34276, 34558, 32902, 31246, 29590, 27934, 26278, 26989, 27700, 28412, 29123, 29834,
+    29038, 28242, 27445, 26649, 25853, 23440, 21028, 18615, 16203, 13790, 11137, 8484, 5832, 3179, 526, 526 };
+static const uint16_t k_deadzonei[52] = {
+    3419, 3419, 3419, 3419, 3419, 3419, 3419, 3419, 3419, 3419, 30550, 8845, 14271, 19698, 25124, 30550, 29556, 28562, 27569, 26575,
+    25581, 25284, 24988, 24691, 24395, 24098, 24116, 24134, 24153, 24171, 24189, 24010, 23832, 23653, 23475, 23296, 23569, 23842,
+    24115, 24388, 24661, 19729, 14797, 9865, 4933, 24661, 3499, 6997, 10495, 13993, 17491, 17491 };
+static const uint8_t k_qpc[52] = {
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32,
+    33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39 };
+/* rate-control model: bits per macroblock at QP 10..50 for P / I frames (h264-lab.h:933-938) */
+static const uint16_t k_bits_per_mb[2][41] = {
+    { 664, 597, 530, 484, 432, 384, 341, 297, 262, 235, 198, 173, 153, 131, 114, 102, 84, 74, 64, 54, 47, 42, 35, 31, 26, 22, 20, 17,
+      15, 13, 12, 10, 9, 9, 7, 7, 6, 5, 4, 1, 1 },
+    { 1057, 975, 925, 868, 803, 740, 694, 630, 586, 547, 496, 457, 420, 378, 345, 318, 284, 258, 234, 210, 190, 178, 155, 141, 129,
+      115, 102, 95, 82, 75, 69, 60, 55, 51, 45, 41, 40, 35, 31, 28, 24 } };
+
+/* h264-lab.h:5822-5834 */
+static uint16_t rnd2thr(int round, int q)
+{
+    int b, thr = 0;
+    for (b = 0x8000; b; b >>= 1)
+        if ((thr | b)*q <= 0x10000 - round) thr |= b;
+    return (uint16_t)thr;
+}
+
+/* h264-lab.h:5839-5912 rc_set_qp: quantizer tables for luma [0] and chroma [1] */
+static void build_qdat(uint16_t qdat[2][42], int qp, int p_slice)
+{
+    static const int16_t qc[6][6] = {
+        { 13107, 10, 8066, 13, 5243, 16 }, { 11916, 11, 7490, 14, 4660, 18 }, { 10082, 13, 6554, 16, 4194, 20 },
+        {  9362, 14, 5825, 18, 3647, 23 }, {  8192, 16, 5243, 20, 3355, 25 }, {  7282, 18, 4559, 23, 2893, 29 } };
+    int c, i, k;
+    for (c = 0; c < 2; c++)
+    {
+        uint16_t *d = qdat[c];
+        int div6 = qp*86 >> 9, mod6 = qp - div6*6;
+        for (i = 0; i < 3; i++)
+        {
+            d[2*i]     = (uint16_t)(qc[mod6][2*i] << 1 >> div6);
+            d[2*i + 1] = (uint16_t)(qc[mod6][2*i + 1] << div6);
+        }
+        d[6] = p_slice ? k_rnd_inter[qp] : k_deadzonei[qp];
+        d[7] = k_deadzonei[qp];
+        d[8] = (uint16_t)(k_thr_inter[qp] - 0x7fff);
+        d[9] = (uint16_t)(k_thr_inter2[qp] - 0x7fff);
+        for (k = 0; k < 2; k++)
+        {
+            uint16_t *t = d + 10 + 8*k;
+            int r = (k ? k_thr_inter2[qp] : k_thr_inter[qp]) - 0x7fff;
+            t[0] = t[2] = rnd2thr(r, d[0]);
+            t[1] = t[3] = t[4] = t[6] = rnd2thr(r, d[2]);
+            t[5] = t[7] = rnd2thr(r, d[4]);
+        }
+        for (k = 0; k < 2; k++)
+        {
+            uint16_t *t = d + 26 + 8*k;
+            t[0] = t[2] = d[k]; t[1] = t[3] = t[4] = t[6] = d[2 + k]; t[5] = t[7] = d[4 + k];
+        }
+        qp = k_qpc[qp];
+    }
+}
+
+/* ------------------------------------------------------------------ header bits / NAL */
+
+typedef struct { uint64_t acc; int n; uint8_t *buf; size_t pos; } hbits_t;     /* small MSB-first writer */
+
+static void hb_put(hbits_t *b, int n, uint32_t v)
+{
+    b->acc = (b->acc << n) | v;
+    b->n += n;
+    while (b->buf && b->n >= 8)
+    {
+        b->n -= 8;
+        b->buf[b->pos++] = (uint8_t)(b->acc >> b->n);
+    }
+}
+static void hb_ue(hbits_t *b, uint32_t v)
+{
+    int size = 0;
+    uint32_t t = v + 1;
+    do size++; while (t >>= 1);
+    hb_put(b, 2*size - 1, v + 1);
+}
+static void hb_se(hbits_t *b, int v) { hb_ue(b, (uint32_t)(v > 0 ? 2*v - 1 : -2*v)); }
+
+/* h264-lab.h:3926-4022: 4-byte start code + payload with emulation prevention; returns bytes written */
+static size_t nal_emit(uint8_t *d, const uint8_t *p, size_t n)
+{
+    size_t i, j = 4;
+    int zeros = 0;
+    d[0] = d[1] = d[2] = 0; d[3] = 1;
+    for (i = 0; i < n; i++)
+    {
+        if (zeros == 2 && p[i] <= 3) { d[j++] = 3; zeros = 0; }
+        zeros = p[i] ? 0 : zeros + 1;
+        d[j++] = p[i];
+    }
+    return j;
+}
+
+static size_t nal_escaped_size(const uint8_t *p, size_t n)
+{
+    size_t i, extra = 0;
+    int zeros = 0;
+    for (i = 0; i < n; i++)
+    {
+        if (zeros == 2 && p[i] <= 3) { extra++; zeros = 0; }
+        zeros = p[i] ? 0 : zeros + 1;
+    }
+    return 4 + n + extra;
+}
+
+typedef struct
+{
+    int width, height, nmbx, nmby, nmb, w, h, cropping;
+    int vbv_size_bytes, sps_id;
+} seq_t;
+
+static void seq_init(seq_t *s, int width, int height, int vbv, int sps_id)
+{
+    s->width = width; s->height = height;
+    s->nmbx = (width + 15) >> 4; s->nmby = (height + 15) >> 4; s->nmb = s->nmbx*s->nmby;
+    s->w = s->nmbx*16; s->h = s->nmby*16;
+    s->cropping = !!((width | height) & 15);
+    s->vbv_size_bytes = vbv; s->sps_id = sps_id;
+}
+
+/* h264-lab.h:4040-4141 encode_sps (profile 66) + h264-lab.h:4147-4176 encode_pps; returns bytes appended to d */
+static size_t write_sps_pps(const seq_t *s, int pic_init_qp, uint8_t *d)
+{
+    static const struct { uint8_t level; uint16_t max_fs, max_vbvdiv5; uint32_t max_dpb; } lim[] = {
+        { 10, 99, 175/5, 396 }, { 10, 99, 350/5, 396 }, { 11, 396, 500/5, 900 }, { 12, 396, 1000/5, 2376 },
+        { 13, 396, 2000/5, 2376 }, { 20, 396, 2000/5, 2376 }, { 21, 792, 4000/5, 4752 }, { 22, 1620, 4000/5, 8100 },
+        { 30, 1620, 10000/5, 8100 }, { 31, 3600, 14000/5, 18000 }, { 32, 5120, 20000/5, 20480 }, { 40, 8192, 25000/5, 32768 },
+        { 41, 8192, 62500/5, 32768 }, { 42, 8704, 62500/5, 34816 }, { 50, 22080, 135000/5, 110400 }, { 51, 36864, 240000/5, 184320 } };
+    uint8_t tmp[64];
+    hbits_t b;
+    size_t n = 0;
+    int k = 0;
+    while (lim[k].level < 51 && (s->nmb > lim[k].max_fs || s->vbv_size_bytes > lim[k].max_vbvdiv5*(5*1000/8) ||
+                                 (unsigned)s->nmb > lim[k].max_dpb)) k++;
+    memset(&b, 0, sizeof(b)); b.buf = tmp;
+    hb_put(&b, 8, 0x67); hb_put(&b, 8, 66); hb_put(&b, 8, 0); hb_put(&b, 8, lim[k].level);
+    hb_ue(&b, (uint32_t)s->sps_id);
+    hb_ue(&b, 1);                                   /* log2_max_frame_num_minus4 */
+    hb_ue(&b, 2);                                   /* pic_order_cnt_type */
+    hb_ue(&b, 1);                                   /* num_ref_frames */
+    hb_put(&b, 1, 0);
+    hb_ue(&b, (uint32_t)(s->nmbx - 1));
+    hb_ue(&b, (uint32_t)(s->nmby - 1));
+    hb_put(&b, 3, (uint32_t)(6 + s->cropping));
+    if (s->cropping)
+    {
+        hb_ue(&b, 0); hb_ue(&b, (uint32_t)((s->w - s->width) >> 1));
+        hb_ue(&b, 0); hb_ue(&b, (uint32_t)((s->h - s->height) >> 1));
+    }
+    hb_put(&b, 1, 0);
+    hb_put(&b, 1, 1);
+    if (b.n) hb_put(&b, 8 - b.n, 0);
+    n += nal_emit(d + n, tmp, b.pos);
+
+    memset(&b, 0, sizeof(b)); b.buf = tmp;
+    hb_put(&b, 8, 0x68);
+    hb_ue(&b, (uint32_t)(s->sps_id*4)); hb_ue(&b, (uint32_t)s->sps_id);
+    hb_put(&b, 1, 0); hb_put(&b, 1, 0);
+    hb_ue(&b, 0); hb_ue(&b, 0); hb_ue(&b, 0);
+    hb_put(&b, 1, 0); hb_put(&b, 2, 0);
+    hb_se(&b, pic_init_qp - 26);
+    hb_put(&b, 5, 0x1C);
+    hb_put(&b, 1, 1);
+    if (b.n) hb_put(&b, 8 - b.n, 0);
+    n += nal_emit(d + n, tmp, b.pos);
+    return n;
+}
+
+/* h264-lab.h:4182-4333 encode_slice_header for KEY / P frames: NAL header byte + header as <= 64 bits */
+static void slice_header_bits(const seq_t *s, int key, int frame_num, int idr_pic_id, int qp, int pic_init_qp, int no_deblock,
+                              uint64_t *bits, int *nbits)
+{
+    hbits_t b;
+    memset(&b, 0, sizeof(b));
+    hb_put(&b, 8, key ? 0x65 : 0x61);
+    hb_ue(&b, 0);
+    hb_ue(&b, key ? SLICE_I : SLICE_P);
+    hb_ue(&b, (uint32_t)(s->sps_id*4));
+    hb_put(&b, 5, (uint32_t)(frame_num & 31));
+    if (key) hb_ue(&b, (uint32_t)idr_pic_id);
+    if (!key) hb_put(&b, 2, 0);
+    if (key) hb_put(&b, 2, 0); else hb_put(&b, 1, 0);
+    hb_se(&b, qp - pic_init_qp);
+    hb_ue(&b, (uint32_t)no_deblock);
+    if (no_deblock != 1) hb_put(&b, 2, 3);
+    *bits = b.acc;
+    *nbits = b.n;
+}
+
+/* ------------------------------------------------------------------ mv_clusters validation */
+
+static int mvx(int32_t v) { return (int16_t)(v & 0xffff); }
+static int mvy(int32_t v) { return (int16_t)((uint32_t)v >> 16); }
+static int32_t mvmk(int x, int y) { return (int32_t)(((uint32_t)y << 16) | ((uint32_t)x & 0xffff)); }
+static int32_t mvround(int32_t a) { return mvmk((mvx(a) + 1) & ~3, (mvy(a) + 1) & ~3); }
+
+/* h264-lab.h:5263-5278 mv_clusters_update */
+static void clusters_step(int32_t c[2], int32_t mv)
+{
+    int n = mvx(mv)*mvx(mv) + mvy(mv)*mvy(mv);
+    int n0 = mvx(c[0])*mvx(c[0]) + mvy(c[0])*mvy(c[0]), n1 = mvx(c[1])*mvx(c[1]) + mvy(c[1])*mvy(c[1]);
+    if (n < n1) c[0] = mvmk((63*mvx(c[0]) + mvx(mv) + 32) >> 6, (63*mvy(c[0]) + mvy(mv) + 32) >> 6);
+    if (n >= n0) c[1] = mvmk((63*mvx(c[1]) + mvx(mv) + 32) >> 6, (63*mvy(c[1]) + mvy(mv) + 32) >> 6);
+}
+
+/*
+ * Walk one frame's macroblock records from state `c` (updated in place).  `used` is what the kernel was
+ * given: one pair for the whole frame (per_mb = 0) or one pair per macroblock.  traj (optional, [nmb][2])
+ * receives the exact value in front of every macroblock.  Returns the first macroblock whose consumed,
+ * rounded candidates differ from the exact ones, or -1.
+ */
+static int clusters_walk(int32_t c[2], const h264e_hip_mbrec_t *rec, int nmb, const int32_t *used, int per_mb, int32_t *traj)
+{
+    int i, first_bad = -1;
+    for (i = 0; i < nmb; i++)
+    {
+        const int32_t *u = per_mb ? used + 2*i : used;
+        if (traj) { traj[2*i] = c[0]; traj[2*i + 1] = c[1]; }
+        if (rec[i].used_cand && first_bad < 0 && (mvround(u[0]) != mvround(c[0]) || mvround(u[1]) != mvround(c[1]))) first_bad = i;
+        if (rec[i].type < 5) clusters_step(c, rec[i].mv0);
+    }
+    return first_bad;
+}
+
+/* ------------------------------------------------------------------ rate control (frame level) */
+
+typedef struct { int qp, prev_qp, vbv_bits, qp_smooth, dqp_smooth, max_dqp, bit_budget, vbv_target_level; } rc_t;
+
+static uint32_t mul32x32shr16(uint32_t x, uint32_t y)               /* h264-lab.h:3420 */
+{
+    return (x >> 16)*(y & 0xFFFFu) + x*(y >> 16) + ((y & 0xFFFFu)*(x & 0xFFFFu) >> 16);
+}
+static uint32_t div_q16(uint32_t numer, uint32_t denum)             /* h264-lab.h:3430 */
+{
+    unsigned f = 1u << __builtin_clz(denum);
+    do
+    {
+        denum = denum*f >> 16;
+        numer = mul32x32shr16(numer, f);
+        f = ((1 << 17) - denum);
+    } while (denum != 0xffff);
+    return numer;
+}
+
+/* h264-lab.h:5924-6070 rc_frame_start without long-term references; returns the frame QP */
+static int rc_frame_start(rc_t *rc, int gop, int nmb, int vbv_size_bytes, int desired_frame_bytes, int qp_min, int qp_max, int is_intra)
+{
+    unsigned np = (unsigned)(gop - 1u) < 63u ? (unsigned)(gop - 1u) : 63u;
+    int qp = -1, add_bits, bit_budget = desired_frame_bytes*8, nominal_p, gop_bits, stationary;
+    uint32_t peak_q16;
+    do
+    {
+        qp++;
+        gop_bits = (int)(k_bits_per_mb[0][qp]*np + k_bits_per_mb[1][qp]);
+    } while (gop_bits*nmb > (int)(np + 1)*desired_frame_bytes*8 && qp < 40);
+    peak_q16 = div_q16((uint32_t)k_bits_per_mb[1][qp] << 16, (uint32_t)k_bits_per_mb[0][qp] << 16);
+    if (np)
+    {
+        uint32_t ratio = div_q16((np + 1) << 16, (np << 16) + peak_q16);
+        nominal_p = (int)mul32x32shr16((uint32_t)(desired_frame_bytes*8), ratio);
+    } else
+        nominal_p = 0;
+    stationary = imin(vbv_size_bytes*8 >> 4, desired_frame_bytes*8);
+    if (is_intra)
+        add_bits = (int)mul32x32shr16((uint32_t)nominal_p, peak_q16) - bit_budget;
+    else
+    {
+        add_bits = nominal_p - bit_budget;
+        if (vbv_size_bytes) add_bits += (rc->vbv_target_level - rc->vbv_bits) >> 4;
+    }
+    if (vbv_size_bytes) add_bits = imin(add_bits, (vbv_size_bytes*8*7 >> 3) - rc->vbv_bits);
+    bit_budget += add_bits;
+    bit_budget = imin(bit_budget, desired_frame_bytes*8*16);
+    bit_budget = imax(bit_budget, desired_frame_bytes*8 >> 2);
+    if (is_intra) rc->vbv_target_level = rc->vbv_bits + bit_budget - desired_frame_bytes*8;
+    rc->vbv_target_level -= desired_frame_bytes*8 - nominal_p;
+    rc->vbv_target_level = imax(rc->vbv_target_level, stationary);
+    rc->bit_budget = bit_budget;
+    {
+        const uint16_t *bits = k_bits_per_mb[!!is_intra];
+        for (qp = 0; qp < 42 - 1; qp++)
+            if (bits[qp]*nmb < bit_budget) break;
+    }
+    qp += 10;
+    qp += rc->dqp_smooth;
+    if (rc->prev_qp > qp + 1) qp = (rc->prev_qp + qp + 1)/2;
+    qp = imin(qp, qp_max); qp = imax(qp, qp_min); qp = imin(qp, 51);             /* h264-lab.h:5841-5843 */
+    rc->qp = qp;
+    rc->qp_smooth = qp << 8;
+    rc->prev_qp = qp;
+    return qp;
+}
+
+/* h264-lab.h:6075-6141 rc_frame_end (stuffing / empty-frame options are refused at init) */
+static void rc_frame_end(rc_t *rc, int nmb, int vbv_size_bytes, int desired_frame_bytes, int out_bytes, int intra, int all_skipped)
+{
+    if (!all_skipped)
+    {
+        int qp;
+        for (qp = 0; qp != 41 && k_bits_per_mb[intra][qp]*nmb > out_bytes*8 - 32; qp++) {}
+        qp += 10;
+        if ((rc->qp_smooth >> 8) - rc->dqp_smooth < qp - 1) rc->dqp_smooth--;
+        else if ((rc->qp_smooth >> 8) - rc->dqp_smooth > qp + 1) rc->dqp_smooth++;
+        if (intra) rc->max_dqp = rc->dqp_smooth;
+        else rc->max_dqp = imax(rc->max_dqp, (rc->qp_smooth >> 8) - qp);
+    }
+    rc->vbv_bits += out_bytes*8 - desired_frame_bytes*8;
+    if (vbv_size_bytes)
+    {
+        if (rc->vbv_bits < 0) rc->vbv_bits = 0;
+        if (rc->vbv_bits > vbv_size_bytes*8) rc->vbv_bits = vbv_size_bytes*8;
+    } else
+        rc->vbv_bits = 0;
+}
+
+/* ------------------------------------------------------------------ one frame on one chain, validated */
+
+/*
+ * Encode one frame on `chain` and make the mv_clusters speculation exact: submit with the frame-constant
+ * value; when the kernel reports that some update would move the state, walk the exact trajectory and, if a
+ * consumed rounded candidate differs, re-encode with per-macroblock values until the walk is consistent
+ * (every pass fixes at least the first offending macroblock, so this terminates).
+ */
+static int encode_frame_exact(h264e_hip_pool_t *pool, int nchains, int chain, h264e_hip_task_t *task, int nmb,
+                              int32_t clusters[2], h264e_hip_result_t *res, int *passes)
+{
+    h264e_hip_task_t *tasks = (h264e_hip_task_t *)calloc((size_t)nchains, sizeof(*tasks));
+    h264e_hip_mbrec_t *rec = NULL;
+    int32_t *traj = NULL, *used = NULL;
+    int rc = -1, pass;
+    if (!tasks) return -1;
+    task->mv_clusters[0] = clusters[0]; task->mv_clusters[1] = clusters[1];
+    task->mv_clusters_per_mb = NULL;
+    for (pass = 0; pass < nmb + 2; pass++)
+    {
+        int32_t c[2] = { clusters[0], clusters[1] };
+        int bad;
+        tasks[chain] = *task;
+        if (h264e_hip_submit(pool, tasks) || h264e_hip_sync(pool) || h264e_hip_result(pool, chain, task->frame_slot, res)) goto done;
+        if (res->overflow) { snprintf(g_host_err, sizeof(g_host_err), "bit buffer overflow"); goto done; }
+        if (!task->mv_clusters_per_mb && !res->clusters_moved) { rc = 0; break; }      /* fixed point: nothing to do */
+        if (!rec)
+        {
+            rec = (h264e_hip_mbrec_t *)malloc(sizeof(*rec)*(size_t)nmb);
+            traj = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb);
+            used = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb);
+            if (!rec || !traj || !used) goto done;
+        }
+        if (h264e_hip_read_mbrec(pool, chain, task->frame_slot, rec)) goto done;
+        bad = clusters_walk(c, rec, nmb, task->mv_clusters_per_mb ? used : task->mv_clusters, task->mv_clusters_per_mb != NULL, traj);
+        if (bad < 0)
+        {
+            clusters[0] = c[0]; clusters[1] = c[1];
+            rc = 0;
+            break;
+        }
+        memcpy(used, traj, sizeof(int32_t)*2*(size_t)nmb);
+        task->mv_clusters_per_mb = used;
+        if (h264e_hip_rewind_frame(pool, chain)) goto done;
+    }
+    if (passes) *passes = pass + 1;
+done:
+    free(tasks); free(rec); free(traj); free(used);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ drop-in API */
+
+typedef struct
+{
+    uint32_t magic, serial;
+    int impl;                               /* index into g_impl: device resources live OUTSIDE the caller's blob */
+    H264E_create_param_t param;
+    H264E_run_param_t run_param;
+    seq_t seq;
+    int frame_num, next_idr_pic_id, pic_init_qp;
+    int32_t clusters[2];
+    rc_t rc;
+} henc_t;
+
+/* The reference API has no destructor and callers simply free() the blob, so nothing that needs
+ * releasing may be reachable only through it: pools and staging buffers sit in this registry, keyed by blob address. */
+typedef struct { void *owner; uint32_t serial; h264e_hip_pool_t *pool; uint8_t *rbsp; size_t rbsp_cap; uint8_t *recon; } impl_t;
+#define MAX_LIVE 64
+static impl_t g_impl[MAX_LIVE];
+static uint32_t g_serial;
+static int g_atexit;
+
+static void impl_release(impl_t *m)
+{
+    if (m->pool) h264e_hip_pool_destroy(m->pool);
+    free(m->rbsp); free(m->recon);
+    memset(m, 0, sizeof(*m));
+}
+
+static void release_all(void)
+{
+    int i;
+    for (i = 0; i < MAX_LIVE; i++) if (g_impl[i].owner) impl_release(g_impl + i);
+}
+
+static impl_t *impl_of(const henc_t *e)
+{
+    if (!e || e->magic != MAGIC || e->impl < 0 || e->impl >= MAX_LIVE) return NULL;
+    if (g_impl[e->impl].owner != (const void *)e || g_impl[e->impl].serial != e->serial) return NULL;
+    return g_impl + e->impl;
+}
+
+void H264E_close(H264E_persist_t *p)
+{
+    int i;
+    for (i = 0; i < MAX_LIVE; i++)
+        if (p && g_impl[i].owner == (void *)p) impl_release(g_impl + i);
+}
+
+/* h264-lab.h:6252-6286 enc_check_create_params (+ the options this implementation refuses) */
+static int check_params(const H264E_create_param_t *par)
+{
+    if (!par) return H264E_STATUS_BAD_ARGUMENT;
+    if ((int)(par->vbv_size_bytes | par->gop) < 0) return H264E_STATUS_BAD_PARAMETER;
+    if (par->width <= 0 || par->height <= 0) return H264E_STATUS_BAD_PARAMETER;
+    if ((unsigned)(par->const_input_flag | par->fine_rate_control_flag | par->vbv_overflow_empty_frame_flag | par->vbv_underflow_stuffing_flag) > 1)
+        return H264E_STATUS_BAD_PARAMETER;
+    if ((unsigned)par->max_long_term_reference_frames > 8) return H264E_STATUS_BAD_PARAMETER;
+    if ((par->width | par->height) & 1) return H264E_STATUS_SIZE_NOT_MULTIPLE_2;
+    if (((par->width | par->height) & 15) && !par->const_input_flag) return H264E_STATUS_SIZE_NOT_MULTIPLE_16;
+    return H264E_STATUS_SUCCESS;
+}
+
+static int unsupported(const H264E_create_param_t *par)
+{
+    return par->max_long_term_reference_frames || par->temporal_denoise_flag || par->fine_rate_control_flag ||
+           par->vbv_overflow_empty_frame_flag || par->vbv_underflow_stuffing_flag || par->num_layers > 1;
+}
+
+/* the reference's blob sizes (h264-lab.h:6191-6230 enc_alloc / enc_alloc_scratch with sizeof(h264e_enc_t) = 1184,
+ * sizeof(scratch_t) = 2962 on LP64): encode_app prints them, and callers size their buffers with them */
+static void ref_sizes(const H264E_create_param_t *par, int *persist, int *scratch)
+{
+    int nmbx = (par->width + 15) >> 4, nmby = (par->height + 15) >> 4, p = 1;
+    int nref = 1 + par->max_long_term_reference_frames + par->const_input_flag + !!par->temporal_denoise_flag;
+    static const int a16 = 15;
+    *persist = (((16 + (nmbx + 2)*(nmby + 2)*384*nref) - 1 + 15) & ~15) + 1184;
+#define ALLOC(sz) p = (p + a16) & ~a16; p += (sz)
+    ALLOC(2962);
+    ALLOC(nmbx*nmby*(384 + 2 + 10)*3/2);
+    ALLOC(nmbx*8 + 8);
+    ALLOC((nmbx*4 + 8)*4);
+    ALLOC(nmbx*4 + 4);
+    ALLOC(nmbx);
+    ALLOC(nmbx);
+    ALLOC(nmbx);
+    ALLOC(nmbx*32 + 32 + 16);
+#undef ALLOC
+    *scratch = p - 1;
+}
+
+int H264E_sizeof(const H264E_create_param_t *par, int *sizeof_persist, int *sizeof_scratch)
+{
+    int err = check_params(par);
+    if (!sizeof_persist || !sizeof_scratch) err = H264E_STATUS_BAD_ARGUMENT;
+    if (err) return err;
+    ref_sizes(par, sizeof_persist, sizeof_scratch);
+    return H264E_STATUS_SUCCESS;
+}
+
+int H264E_init(H264E_persist_t *p, const H264E_create_param_t *par)
+{
+    henc_t *e = (henc_t *)p;
+    impl_t *m;
+    int i, err = check_params(par);
+    g_host_err[0] = 0;
+    if (!e) return H264E_STATUS_BAD_ARGUMENT;
+    if (err) return err;
+    if (unsupported(par))
+    {
+        snprintf(g_host_err, sizeof(g_host_err), "option outside the MI355X encode path (long-term refs, denoise, MB-level RC, VBV stuffing/empty frames, SVC)");
+        return H264E_STATUS_BAD_PARAMETER;
+    }
+    H264E_close(p);                             /* re-init of the same blob: drop the old device state */
+    for (i = 0; i < MAX_LIVE && g_impl[i].owner; i++) {}
+    if (i == MAX_LIVE)
+    {
+        snprintf(g_host_err, sizeof(g_host_err), "too many live encoders (%d): call H264E_close", MAX_LIVE);
+        return H264E_STATUS_BAD_ARGUMENT;
+    }
+    m = g_impl + i;
+    memset(e, 0, sizeof(*e));
+    e->param = *par;
+    seq_init(&e->seq, par->width, par->height, par->vbv_size_bytes, par->sps_id);
+    if (h264e_hip_pool_create(&m->pool, pick_device(), par->width, par->height, 1, 1, 1))
+        return H264E_STATUS_BAD_ARGUMENT;       /* no device: the HIP path is the only path */
+    m->rbsp_cap = (size_t)e->seq.nmb*640 + 2048;
+    m->rbsp = (uint8_t *)malloc(m->rbsp_cap);
+    if (!par->const_input_flag) m->recon = (uint8_t *)malloc((size_t)e->seq.w*e->seq.h*3/2);
+    m->owner = e;
+    m->serial = e->serial = ++g_serial;
+    e->impl = i;
+    e->magic = MAGIC;
+    if (!g_atexit) { atexit(release_all); g_atexit = 1; }
+    return H264E_STATUS_SUCCESS;
+}
+
+void H264E_set_vbv_state(H264E_persist_t *p, int vbv_size_bytes, int vbv_fullness_bytes)
+{
+    henc_t *e = (henc_t *)p;
+    if (!e || e->magic != MAGIC) return;
+    e->param.vbv_size_bytes = vbv_size_bytes;
+    e->seq.vbv_size_bytes = vbv_size_bytes;
+    if (vbv_fullness_bytes >= 0)
+    {
+        e->rc.vbv_bits = vbv_fullness_bytes*8;
+        e->rc.vbv_target_level = e->rc.vbv_bits;
+    }
+}
+
+int H264E_encode(H264E_persist_t *p, H264E_scratch_t *scratch, const H264E_run_param_t *opt, H264E_io_yuv_t *in,
+                 unsigned char **coded_data, int *sizeof_coded_data)
+{
+    henc_t *e = (henc_t *)p;
+    impl_t *m = impl_of(e);
+    uint8_t *out = (uint8_t *)scratch;
+    size_t out_pos = 0, cap;
+    int frame_type, key, qp, sp, ss, n;
+    h264e_hip_task_t task;
+    h264e_hip_result_t res;
+    const uint8_t *yuv[3];
+    g_host_err[0] = 0;
+    if (!m || !scratch || !in || !coded_data || !sizeof_coded_data) return H264E_STATUS_BAD_ARGUMENT;
+    ref_sizes(&e->param, &sp, &ss);
+    cap = (size_t)ss;
+    if (opt) e->run_param = *opt;
+    opt = &e->run_param;
+    if (!e->run_param.qp_max || e->run_param.qp_max > 51) e->run_param.qp_max = 51;       /* h264-lab.h:6707-6715 */
+    if (!e->run_param.qp_min || e->run_param.qp_min < 10) e->run_param.qp_min = 10;
+    if (opt->desired_nalu_bytes)
+    {
+        snprintf(g_host_err, sizeof(g_host_err), "desired_nalu_bytes (multi-slice) is outside the MI355X encode path");
+        return H264E_STATUS_BAD_ARGUMENT;
+    }
+
+    frame_type = opt->frame_type;
+    if (frame_type == H264E_FRAME_TYPE_DEFAULT) frame_type = e->frame_num ? H264E_FRAME_TYPE_P : H264E_FRAME_TYPE_KEY;
+    if (frame_type != H264E_FRAME_TYPE_KEY && frame_type != H264E_FRAME_TYPE_P) return H264E_STATUS_BAD_FRAME_TYPE;
+    key = frame_type == H264E_FRAME_TYPE_KEY;
+    if (key)
+    {
+        e->pic_init_qp = imax(imin(30, e->run_param.qp_max), e->run_param.qp_min);       /* h264-lab.h:6768-6775 */
+        e->next_idr_pic_id ^= 1;
+        e->frame_num = 0;
+        out_pos += write_sps_pps(&e->seq, e->pic_init_qp, out + out_pos);
+    } else if (!e->pic_init_qp)
+        return H264E_STATUS_BAD_FRAME_TYPE;                                              /* h264-lab.h:6801-6804 */
+
+    qp = rc_frame_start(&e->rc, e->param.gop, e->seq.nmb, e->param.vbv_size_bytes, opt->desired_frame_bytes,
+                        e->run_param.qp_min, e->run_param.qp_max, key);
+
+    memset(&task, 0, sizeof(task));
+    task.active = 1; task.frame_index = 0; task.frame_slot = 0;
+    task.slice_type = key ? SLICE_I : SLICE_P;
+    task.qp = qp; task.speed = opt->encode_speed;
+    slice_header_bits(&e->seq, key, e->frame_num, e->next_idr_pic_id, qp, e->pic_init_qp,
+                      (opt->encode_speed == 8 || opt->encode_speed == 10), &task.hdr_bits, &task.hdr_nbits);
+    build_qdat(task.qdat, qp, !key);
+
+    yuv[0] = in->yuv[0]; yuv[1] = in->yuv[1]; yuv[2] = in->yuv[2];
+    if (h264e_hip_reset_results(m->pool, 0) || h264e_hip_upload_planes(m->pool, 0, yuv, in->stride)) return H264E_STATUS_BAD_ARGUMENT;
+    if (encode_frame_exact(m->pool, 1, 0, &task, e->seq.nmb, e->clusters, &res, NULL)) return H264E_STATUS_BAD_ARGUMENT;
+    if (res.nbytes > m->rbsp_cap) return H264E_STATUS_BAD_ARGUMENT;
+    n = h264e_hip_read_rbsp(m->pool, 0, 0, m->rbsp, (uint32_t)m->rbsp_cap);
+    if (n < 0) return H264E_STATUS_BAD_ARGUMENT;
+    if (out_pos + nal_escaped_size(m->rbsp, (size_t)n) > cap)
+    {
+        snprintf(g_host_err, sizeof(g_host_err), "coded frame does not fit the scratch blob");
+        return H264E_STATUS_BAD_ARGUMENT;
+    }
+    out_pos += nal_emit(out + out_pos, m->rbsp, (size_t)n);
+    if (opt->nalu_callback)
+        opt->nalu_callback(out + out_pos - (nal_escaped_size(m->rbsp, (size_t)n) - 4), (int)(nal_escaped_size(m->rbsp, (size_t)n) - 4), opt->nalu_callback_token);
+
+    rc_frame_end(&e->rc, e->seq.nmb, e->param.vbv_size_bytes, opt->desired_frame_bytes, (int)out_pos, key, res.all_skipped);
+
+    if (!e->param.const_input_flag)
+    {
+        /* h264-lab.h:6719-6723: the reconstruction replaces the caller's input picture (encode_app --psnr relies on it) */
+        int c, y;
+        const uint8_t *s = m->recon;
+        if (h264e_hip_read_recon(m->pool, 0, m->recon)) return H264E_STATUS_BAD_ARGUMENT;
+        for (c = 0; c < 3; c++)
+        {
+            int w = e->seq.w >> (c ? 1 : 0), h = e->seq.h >> (c ? 1 : 0);
+            for (y = 0; y < h; y++) memcpy(in->yuv[c] + (size_t)y*in->stride[c], s + (size_t)y*w, (size_t)w);
+            s += (size_t)w*h;
+        }
+    }
+    if (++e->frame_num >= e->param.gop && e->param.gop && e->run_param.frame_type == H264E_FRAME_TYPE_DEFAULT) e->frame_num = 0;
+    *coded_data = out;
+    *sizeof_coded_data = (int)out_pos;
+    return H264E_STATUS_SUCCESS;
+}
+
+/* ------------------------------------------------------------------ whole-clip encode, GOPs as parallel chains */
+
+struct H264E_clip_tag
+{
+    H264E_clip_param_t par;
+    seq_t seq;
+    int nframes, ngops, nchains, gop_len;
+    h264e_hip_pool_t *pool;
+};
+
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec*1e3 + ts.tv_nsec*1e-6;
+}
+
+int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nframes)
+{
+    H264E_clip_t *c;
+    g_host_err[0] = 0;
+    if (!out || !par || nframes <= 0 || par->width <= 0 || par->height <= 0 || ((par->width | par->height) & 1) || par->gop < 0) return -1;
+    c = (H264E_clip_t *)calloc(1, sizeof(*c));
+    if (!c) return -1;
+    c->par = *par;
+    c->par.qp = imin(imax(par->qp, 10), 51);
+    seq_init(&c->seq, par->width, par->height, par->vbv_size_bytes, 0);
+    c->nframes = nframes;
+    c->gop_len = par->gop ? par->gop : nframes;
+    c->ngops = (nframes + c->gop_len - 1)/c->gop_len;
+    c->nchains = par->max_chains > 0 ? imin(par->max_chains, c->ngops) : c->ngops;
+    if (h264e_hip_pool_create(&c->pool, par->device, par->width, par->height, c->nchains, nframes, c->gop_len))
+    {
+        free(c);
+        return -1;
+    }
+    *out = c;
+    return 0;
+}
+
+void H264E_clip_close(H264E_clip_t *c)
+{
+    if (!c) return;
+    h264e_hip_pool_destroy(c->pool);
+    free(c);
+}
+
+int H264E_clip_upload(H264E_clip_t *c, int first, int nframes, const uint8_t *i420)
+{
+    if (!c) return -1;
+    if (h264e_hip_upload_i420(c->pool, first, nframes, i420)) return -1;
+    return h264e_hip_sync(c->pool);
+}
+
+int H264E_clip_generate_synth(H264E_clip_t *c, int first, int nframes, int t0, uint32_t seed)
+{
+    if (!c) return -1;
+    if (h264e_hip_generate_synth(c->pool, first, nframes, t0, seed)) return -1;
+    return h264e_hip_sync(c->pool);
+}
+
+int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_bytes, int *frame_bytes, int profile, H264E_clip_stats_t *st)
+{
+    const int qp = c->par.qp, nmb = c->seq.nmb, G = c->gop_len, no_deblock = (c->par.speed == 8 || c->par.speed == 10);
+    const int pic_init_qp = imax(imin(30, qp), qp);     /* qp_min = qp_max = qp (h264-lab.h:6768-6770) */
+    h264e_hip_task_t *tasks = (h264e_hip_task_t *)calloc((size_t)c->nchains, sizeof(*tasks));
+    h264e_hip_result_t *res = (h264e_hip_result_t *)calloc((size_t)G, sizeof(*res));
+    uint32_t *offs = (uint32_t *)calloc((size_t)G, sizeof(uint32_t));
+    const uint32_t arena_cap = (uint32_t)((size_t)G*((size_t)nmb*640 + 1024));
+    uint8_t *arena = (uint8_t *)malloc(arena_cap);
+    h264e_hip_mbrec_t *rec = NULL;
+    int32_t clusters[2] = { c->par.mv_clusters_in[0], c->par.mv_clusters_in[1] };
+    int idr_state = c->par.first_idr_pic_id_state & 1;
+    uint16_t qdat_i[2][42], qdat_p[2][42];
+    size_t pos = 0;
+    int round, rc = -1, f, k;
+    H264E_clip_stats_t stats;
+    double t0;
+    memset(&stats, 0, sizeof(stats));
+    g_host_err[0] = 0;
+    if (!tasks || !res || !offs || !arena) goto done;
+    build_qdat(qdat_i, qp, 0);
+    build_qdat(qdat_p, qp, 1);
+    h264e_hip_profile(c->pool, profile);
+    stats.chains = c->nchains;
+
+    for (round = 0; round*c->nchains < c->ngops; round++)
+    {
+        const int g0 = round*c->nchains, ng = imin(c->nchains, c->ngops - g0);
+        stats.rounds++;
+        t0 = now_ms();
+        for (k = 0; k < ng; k++) if (h264e_hip_reset_results(c->pool, k)) goto done;
+        /* every chain speculates the mv_clusters state in front of this round (it rarely moves) */
+        const int32_t spec[2] = { clusters[0], clusters[1] };
+        for (f = 0; f < G; f++)
+        {
+            int any = 0;
+            for (k = 0; k < c->nchains; k++)
+            {
+                h264e_hip_task_t *t = tasks + k;
+                const int g = g0 + k, fi = g*G + f;
+                memset(t, 0, sizeof(*t));
+                if (k >= ng || fi >= c->nframes) continue;
+                any = 1;
+                t->active = 1; t->frame_index = fi; t->frame_slot = f;
+                t->slice_type = f ? SLICE_P : SLICE_I;
+                t->qp = qp; t->speed = c->par.speed;
+                /* idr_pic_id toggles with every key frame (h264-lab.h:6774): GOP g sees state ^ (g + 1 odd) */
+                slice_header_bits(&c->seq, !f, f, (idr_state ^ ((g + 1) & 1)), qp, pic_init_qp, no_deblock, &t->hdr_bits, &t->hdr_nbits);
+                t->mv_clusters[0] = clusters[0]; t->mv_clusters[1] = clusters[1];
+                memcpy(t->qdat, f ? qdat_p : qdat_i, sizeof(t->qdat));
+            }
+            if (any && h264e_hip_submit(c->pool, tasks)) goto done;
+        }
+        if (h264e_hip_sync(c->pool)) goto done;
+        stats.encode_ms += now_ms() - t0;
+
+        for (k = 0; k < ng; k++)
+        {
+            const int g = g0 + k, nf = imin(G, c->nframes - g*G);
+            uint32_t used = 0;
+            int moved = 0, redo_from = -1;
+            t0 = now_ms();
+            if (h264e_hip_read_chain(c->pool, k, nf, res, offs, arena, arena_cap, &used)) goto done;
+            stats.readback_ms += now_ms() - t0;
+            for (f = 0; f < nf; f++)
+            {
+                if (res[f].overflow) { snprintf(g_host_err, sizeof(g_host_err), "bit buffer overflow (GOP %d frame %d)", g, f); goto done; }
+                moved |= res[f].clusters_moved;
+            }
+            if (moved || clusters[0] != spec[0] || clusters[1] != spec[1])
+            {
+                /* exact validation: walk the true trajectory through the GOP's records */
+                int32_t cc[2] = { clusters[0], clusters[1] };
+                if (!rec) rec = (h264e_hip_mbrec_t *)malloc(sizeof(*rec)*(size_t)nmb);
+                if (!rec) goto done;
+                for (f = 0; f < nf && redo_from < 0; f++)
+                {
+                    int32_t before[2] = { cc[0], cc[1] };
+                    if (h264e_hip_read_mbrec(c->pool, k, f, rec)) goto done;
+                    if (clusters_walk(cc, rec, nmb, spec, 0, NULL) >= 0)
+                    {
+                        redo_from = f;
+                        cc[0] = before[0]; cc[1] = before[1];
+                    }
+                }
+                if (redo_from < 0) { clusters[0] = cc[0]; clusters[1] = cc[1]; }
+                else
+                {
+                    /* a consumed candidate differs: re-encode this GOP frame by frame with exact values.  Frames
+                     * before redo_from are valid, but the chain's pictures have moved on, so restart at its key frame. */
+                    int32_t ce[2] = { clusters[0], clusters[1] };
+                    stats.reencoded_gops++;
+                    if (h264e_hip_reset_results(c->pool, k)) goto done;
+                    for (f = 0; f < nf; f++)
+                    {
+                        h264e_hip_task_t t;
+                        h264e_hip_result_t r1;
+                        memset(&t, 0, sizeof(t));
+                        t.active = 1; t.frame_index = g*G + f; t.frame_slot = f;
+                        t.slice_type = f ? SLICE_P : SLICE_I; t.qp = qp; t.speed = c->par.speed;
+                        slice_header_bits(&c->seq, !f, f, (idr_state ^ ((g + 1) & 1)), qp, pic_init_qp, no_deblock, &t.hdr_bits, &t.hdr_nbits);
+                        memcpy(t.qdat, f ? qdat_p : qdat_i, sizeof(t.qdat));
+                        if (encode_frame_exact(c->pool, c->nchains, k, &t, nmb, ce, &r1, NULL)) goto done;
+                    }
+                    clusters[0] = ce[0]; clusters[1] = ce[1];
+                    if (h264e_hip_read_chain(c->pool, k, nf, res, offs, arena, arena_cap, &used)) goto done;
+                    /* re-encoded frames appended their results behind the stale ones: the slot table points at the fresh ones */
+                }
+            }
+            t0 = now_ms();
+            for (f = 0; f < nf; f++)
+            {
+                const uint8_t *rb = arena + offs[f];
+                size_t start = pos, need = nal_escaped_size(rb, res[f].nbytes) + (f ? 0 : 64);
+                if (pos + need > cap) { snprintf(g_host_err, sizeof(g_host_err), "output buffer too small"); goto done; }
+                if (!f) pos += write_sps_pps(&c->seq, pic_init_qp, out + pos);
+                pos += nal_emit(out + pos, rb, res[f].nbytes);
+                if (frame_bytes) frame_bytes[g*G + f] = (int)(pos - start);
+            }
+            stats.assemble_ms += now_ms() - t0;
+        }
+    }
+    stats.mv_clusters_out[0] = clusters[0]; stats.mv_clusters_out[1] = clusters[1];
+    stats.next_idr_pic_id_state = idr_state ^ (c->ngops & 1);
+    h264e_hip_profile_read(c->pool, &stats.mb_kernel_ms, &stats.splice_kernel_ms, &stats.kernel_launches);
+    if (out_bytes) *out_bytes = pos;
+    rc = 0;
+done:
+    if (st) *st = stats;
+    free(tasks); free(res); free(offs); free(arena); free(rec);
+    return rc;
+}

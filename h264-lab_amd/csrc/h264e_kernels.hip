@@ -1,0 +1,626 @@
+/*
+ * h264e_kernels.hip -- HIP kernels of the per-frame encode path and their C-ABI launcher (include/h264e_hip.h).
+ *
+ * Kernels (gfx950, wave64):
+ *   h264e_mb_kernel      one 64-lane workgroup per (chain, macroblock row); rows of one picture run as a
+ *                        wavefront behind each other: row r may encode macroblock x once row r-1 has finished
+ *                        macroblock x+1 (left, top-left, top, top-right neighbours + in-loop deblocking order).
+ *                        The hand-off is a per-row progress counter with agent-scope release/acquire
+ *                        (cdna_hip_programming.md Guideline 16).
+ *   h264e_splice_kernel  one workgroup per chain: concatenates the row bit buffers into the slice RBSP.
+ *   h264e_synth_kernel   fills resident input frames with the synth_v1 clip (bench / test input in HBM).
+ *
+ * Built as the product with hipcc --offload-arch=gfx950.  The same file compiles with g++ -DH264E_EMU into
+ * a lane-loop emulation that only tests/ use (see wave.h); the product library never contains that path.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "enc_row.h"
+#include "../../include/h264e_hip.h"
+
+#ifndef H264E_EMU
+#include <hip/hip_runtime.h>
+#endif
+
+static char g_err[256];
+#define FAIL(...) do { snprintf(g_err, sizeof(g_err), __VA_ARGS__); return -1; } while (0)
+extern "C" const char *h264e_hip_last_error(void) { return g_err; }
+
+/* ------------------------------------------------------------------ device code */
+
+#ifndef H264E_EMU
+
+#define SPIN_LIMIT (1u << 22)
+
+__global__ void __launch_bounds__(64) h264e_mb_kernel(h264e_geom_t G, const h264e_chain_dev_t *chains,
+                                                      const h264e_frame_task_t *tasks, int nchains, int *errflag)
+{
+    __shared__ RowLds L;
+    const int chain = (int)(blockIdx.x % (unsigned)nchains), row = (int)(blockIdx.x / (unsigned)nchains);
+    const h264e_frame_task_t &T = tasks[chain];
+    if (!T.active) return;
+    const h264e_chain_dev_t &C = chains[chain];
+    row_begin(L, G, C, T, row);
+    int seen = 0;
+    for (int x = 0; x < G.nmbx; x++)
+    {
+        if (row > 0)
+        {
+            const int need = imin(x + 2, G.nmbx);
+            if (seen < need)
+            {
+                /* consumer: ONE relaxed poll loop, then ONE agent-scope acquire (invalidates this CU's L1) */
+                unsigned spins = 0;
+                int *flag = C.progress + (row - 1);
+                for (;;)
+                {
+                    seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seen >= need) break;
+                    if (++spins > SPIN_LIMIT || seen < 0)
+                    {
+                        /* bounded spin: give up, poison this row's counter so the rows below stop too */
+                        if (threadIdx.x == 0)
+                        {
+                            *errflag = 1;
+                            __hip_atomic_store(C.progress + row, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        return;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+        row_step(L, G, C, T, row, x);
+        /* producer: drain every lane's stores, agent-scope release (L2 write-back), then the counter */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(C.progress + row, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    row_end(L, G, C, row);
+}
+
+__global__ void __launch_bounds__(64) h264e_splice_kernel(h264e_geom_t G, const h264e_chain_dev_t *chains,
+                                                          const h264e_frame_task_t *tasks)
+{
+    const h264e_frame_task_t &T = tasks[blockIdx.x];
+    if (!T.active) return;
+    finalize_frame(G, chains[blockIdx.x], T);
+}
+
+#endif
+
+/* synth_v1 generator, one sample per call */
+DEV uint32_t sv_h32(uint32_t a)
+{
+    a ^= a >> 16; a *= 0x7feb352du; a ^= a >> 15; a *= 0x846ca68bu; a ^= a >> 16;
+    return a;
+}
+DEV int sv_lattice(int32_t ix, int32_t iy, uint32_t seed) { return (int)(sv_h32((uint32_t)ix*0x9E3779B1u ^ (uint32_t)iy*0x85EBCA77u ^ seed) & 255); }
+DEV int sv_tex(int32_t X, int32_t Y, uint32_t seed, int lg)
+{
+    int32_t c = 1 << lg, ix = X >> lg, iy = Y >> lg, fx = X & (c - 1), fy = Y & (c - 1);
+    int32_t a = sv_lattice(ix, iy, seed), b = sv_lattice(ix + 1, iy, seed), cc = sv_lattice(ix, iy + 1, seed), d = sv_lattice(ix + 1, iy + 1, seed);
+    int32_t top = a*(c - fx) + b*fx, bot = cc*(c - fx) + d*fx;
+    return (top*(c - fy) + bot*fy + (1 << (2*lg - 1))) >> (2*lg);
+}
+DEV uint8_t sv_sample(int w, int h, int t, uint32_t seed, int idx)
+{
+    const int32_t OFF = 1 << 20;
+    if (idx < w*h)
+    {
+        int x = idx % w, y = idx / w, fw = w/8 > 32 ? w/8 : 32, fh = h/6 > 32 ? h/6 : 32;
+        int fx0 = (w/2 + ((10*t) >> 2)) % (w - fw), fy0 = h/3, v;
+        if (x >= fx0 && x < fx0 + fw && y >= fy0 && y < fy0 + fh) v = sv_tex(4*x - 10*t + OFF, 4*y + OFF, seed + 1, 5);
+        else v = (sv_tex(4*x + 5*t + OFF, 4*y + 3*t + OFF, seed, 6)*3 >> 2) + 32;
+        v += (int)(sv_h32((uint32_t)x ^ ((uint32_t)y << 12) ^ ((uint32_t)t << 24) ^ (uint32_t)(seed*7919u)) % 5) - 2;
+        return (uint8_t)clip255(v);
+    }
+    idx -= w*h;
+    const int cw = w/2, ch = h/2, pl = idx >= cw*ch;
+    if (pl) idx -= cw*ch;
+    int x = idx % cw, y = idx / cw;
+    if (!pl) return (uint8_t)(128 + ((sv_tex(8*x + 5*t + OFF, 8*y + 3*t + OFF, seed + 2, 7) - 128) >> 2));
+    return (uint8_t)(128 - ((sv_tex(8*x + 5*t + OFF, 8*y + 3*t + OFF, seed + 3, 7) - 128) >> 3));
+}
+
+#ifndef H264E_EMU
+__global__ void h264e_synth_kernel(uint8_t *dst, int w, int h, int t, uint32_t seed)
+{
+    const int n = w*h*3/2;
+    for (int i = (int)(blockIdx.x*blockDim.x + threadIdx.x); i < n; i += (int)(gridDim.x*blockDim.x))
+        dst[i] = sv_sample(w, h, t, seed, i);
+}
+#endif
+
+/* ------------------------------------------------------------------ host side: pool */
+
+#ifdef H264E_EMU
+#define DEVCALL(x) (x)
+static int dev_malloc(void **p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : -1; }
+static void dev_free(void *p) { free(p); }
+#define H2D(d, s, n) memcpy(d, s, n)
+#define D2H(d, s, n) memcpy(d, s, n)
+#else
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) FAIL("%s: %s", #x, hipGetErrorString(e_)); } while (0)
+static int dev_malloc(void **p, size_t n) { return hipMalloc(p, n ? n : 1) == hipSuccess ? 0 : -1; }
+static void dev_free(void *p) { if (p) (void)hipFree(p); }
+#endif
+
+#define TASK_RING 128
+
+struct h264e_hip_pool
+{
+    int device, nchains, frames_resident, slots;
+    h264e_geom_t G;
+    size_t frame_bytes;
+    uint8_t *clip;                       /* device: resident input frames, packed I420 */
+    h264e_chain_dev_t *chains_host;      /* host mirror of the device descriptors */
+    h264e_chain_dev_t *chains_dev;
+    h264e_frame_task_t *tasks_dev;       /* ring of TASK_RING task arrays */
+    int *progress_all;
+    int *errflag;
+    int32_t **clu_dev;                   /* per chain: optional per-macroblock mv_clusters array */
+    int *ref_sel;                        /* per chain */
+    int ring_pos, pending;
+    int profile, prof_launches;
+    double prof_mb_ms, prof_splice_ms;
+#ifndef H264E_EMU
+    hipStream_t stream;
+    hipEvent_t ev_t0, ev_t1;
+    hipEvent_t ev[TASK_RING][3];         /* per pending submit: before / between / after the two kernels */
+    int ev_pending;
+#endif
+};
+
+extern "C" int h264e_hip_device_count(void)
+{
+#ifdef H264E_EMU
+    return 1;
+#else
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+#endif
+}
+
+extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
+{
+    if (!p) return;
+#ifndef H264E_EMU
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+#endif
+    if (p->chains_host)
+        for (int c = 0; c < p->nchains; c++)
+        {
+            h264e_chain_dev_t &C = p->chains_host[c];
+            dev_free(C.rec[0][0]); dev_free(C.bottom); dev_free(C.rowbits); dev_free(C.rowmeta);
+            dev_free(C.mbrec); dev_free(C.arena); dev_free(C.cursor); dev_free(C.fout);
+            if (p->clu_dev) dev_free(p->clu_dev[c]);
+        }
+    dev_free(p->clip); dev_free(p->chains_dev); dev_free(p->tasks_dev); dev_free(p->progress_all); dev_free(p->errflag);
+#ifndef H264E_EMU
+    if (p->stream)
+    {
+        for (int i = 0; i < TASK_RING; i++) for (int k = 0; k < 3; k++) (void)hipEventDestroy(p->ev[i][k]);
+        (void)hipEventDestroy(p->ev_t0); (void)hipEventDestroy(p->ev_t1);
+        (void)hipStreamDestroy(p->stream);
+    }
+#endif
+    free(p->chains_host); free(p->clu_dev); free(p->ref_sel);
+    free(p);
+}
+
+extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int width, int height, int nchains,
+                                     int frames_resident, int slots)
+{
+    if (!pool || width <= 0 || height <= 0 || ((width | height) & 1) || nchains <= 0 || frames_resident <= 0 || slots <= 0)
+        FAIL("h264e_hip_pool_create: bad argument");
+    h264e_hip_pool_t *p = (h264e_hip_pool_t *)calloc(1, sizeof(*p));
+    if (!p) FAIL("out of host memory");
+    p->device = device; p->nchains = nchains; p->frames_resident = frames_resident; p->slots = slots;
+    h264e_geom_t &G = p->G;
+    G.width = width; G.height = height;
+    G.nmbx = (width + 15) >> 4; G.nmby = (height + 15) >> 4; G.nmb = G.nmbx*G.nmby;
+    G.W = G.nmbx*16; G.H = G.nmby*16;
+    G.cropping = !!((width | height) & 15);
+    G.lim_x0 = G.lim_y0 = -14*4;                                    /* h264-lab.h:6322-6324, MV_GUARD 14 */
+    G.lim_x1 = (G.W - 2)*4; G.lim_y1 = (G.H - 2)*4;
+    G.row_words = G.nmbx*(H264E_ROW_BYTES_PER_MB/4);
+    p->frame_bytes = (size_t)width*height*3/2;
+#ifndef H264E_EMU
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    {
+        free(p);
+        FAIL("no HIP device: the HIP path is mandatory (there is no CPU fallback)");
+    }
+    if (hipSetDevice(device) != hipSuccess) { free(p); FAIL("hipSetDevice(%d) failed", device); }
+    if (hipStreamCreate(&p->stream) != hipSuccess) { free(p); FAIL("hipStreamCreate failed"); }
+    for (int i = 0; i < TASK_RING; i++) for (int k = 0; k < 3; k++) (void)hipEventCreate(&p->ev[i][k]);
+    (void)hipEventCreate(&p->ev_t0); (void)hipEventCreate(&p->ev_t1);
+#endif
+    p->chains_host = (h264e_chain_dev_t *)calloc((size_t)nchains, sizeof(h264e_chain_dev_t));
+    p->clu_dev = (int32_t **)calloc((size_t)nchains, sizeof(int32_t *));
+    p->ref_sel = (int *)calloc((size_t)nchains, sizeof(int));
+    int bad = 0;
+    bad |= dev_malloc((void **)&p->clip, p->frame_bytes*(size_t)frames_resident);
+    bad |= dev_malloc((void **)&p->chains_dev, sizeof(h264e_chain_dev_t)*(size_t)nchains);
+    bad |= dev_malloc((void **)&p->tasks_dev, sizeof(h264e_frame_task_t)*(size_t)nchains*TASK_RING);
+    bad |= dev_malloc((void **)&p->progress_all, sizeof(int)*(size_t)nchains*G.nmby);
+    bad |= dev_malloc((void **)&p->errflag, sizeof(int));
+    const size_t plane = (size_t)G.W*G.H*3/2;
+    const uint32_t arena_cap = (uint32_t)((size_t)slots*((size_t)G.nmb*640 + 1024));
+    for (int c = 0; c < nchains && !bad; c++)
+    {
+        h264e_chain_dev_t &C = p->chains_host[c];
+        uint8_t *rec = 0;
+        bad |= dev_malloc((void **)&rec, 2*plane);
+        if (bad) break;
+        for (int k = 0; k < 2; k++)
+        {
+            C.rec[k][0] = rec + k*plane;
+            C.rec[k][1] = C.rec[k][0] + (size_t)G.W*G.H;
+            C.rec[k][2] = C.rec[k][1] + (size_t)G.W*G.H/4;
+        }
+        bad |= dev_malloc((void **)&C.bottom, sizeof(h264e_mbbottom_t)*(size_t)G.nmb);
+        C.progress = p->progress_all + (size_t)c*G.nmby;
+        bad |= dev_malloc((void **)&C.rowbits, sizeof(uint32_t)*(size_t)G.nmby*G.row_words);
+        bad |= dev_malloc((void **)&C.rowmeta, sizeof(h264e_rowmeta_t)*(size_t)G.nmby);
+        bad |= dev_malloc((void **)&C.mbrec, sizeof(h264e_mbrec_t)*(size_t)G.nmb*slots);
+        bad |= dev_malloc((void **)&C.arena, arena_cap);
+        C.arena_cap = arena_cap;
+        bad |= dev_malloc((void **)&C.cursor, 16);
+        bad |= dev_malloc((void **)&C.fout, sizeof(h264e_frameout_t)*(size_t)slots);
+    }
+    if (bad)
+    {
+        h264e_hip_pool_destroy(p);
+        FAIL("device allocation failed");
+    }
+#ifdef H264E_EMU
+    memcpy(p->chains_dev, p->chains_host, sizeof(h264e_chain_dev_t)*(size_t)nchains);
+#else
+    for (int c = 0; c < nchains; c++) (void)hipMemset(p->chains_host[c].cursor, 0, 16);
+    (void)hipMemset(p->errflag, 0, sizeof(int));
+    if (hipMemcpy(p->chains_dev, p->chains_host, sizeof(h264e_chain_dev_t)*(size_t)nchains, hipMemcpyHostToDevice) != hipSuccess)
+    {
+        h264e_hip_pool_destroy(p);
+        FAIL("descriptor upload failed");
+    }
+#endif
+    *pool = p;
+    return 0;
+}
+
+extern "C" int h264e_hip_upload_i420(h264e_hip_pool_t *p, int first, int nframes, const uint8_t *host)
+{
+    if (!p || first < 0 || nframes < 0 || first + nframes > p->frames_resident) FAIL("upload_i420: bad range");
+#ifdef H264E_EMU
+    memcpy(p->clip + p->frame_bytes*(size_t)first, host, p->frame_bytes*(size_t)nframes);
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpyAsync(p->clip + p->frame_bytes*(size_t)first, host, p->frame_bytes*(size_t)nframes, hipMemcpyHostToDevice, p->stream));
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_upload_planes(h264e_hip_pool_t *p, int index, const uint8_t *const yuv[3], const int stride[3])
+{
+    if (!p || index < 0 || index >= p->frames_resident) FAIL("upload_planes: bad index");
+    uint8_t *d = p->clip + p->frame_bytes*(size_t)index;
+    for (int c = 0; c < 3; c++)
+    {
+        const int w = p->G.width >> (c ? 1 : 0), h = p->G.height >> (c ? 1 : 0);
+#ifdef H264E_EMU
+        for (int y = 0; y < h; y++) memcpy(d + (size_t)y*w, yuv[c] + (size_t)y*stride[c], (size_t)w);
+#else
+        HIPCHK(hipSetDevice(p->device));
+        HIPCHK(hipMemcpy2DAsync(d, (size_t)w, yuv[c], (size_t)stride[c], (size_t)w, (size_t)h, hipMemcpyHostToDevice, p->stream));
+#endif
+        d += (size_t)w*h;
+    }
+    return 0;
+}
+
+extern "C" int h264e_hip_generate_synth(h264e_hip_pool_t *p, int first, int nframes, int t0, uint32_t seed)
+{
+    if (!p || first < 0 || nframes < 0 || first + nframes > p->frames_resident) FAIL("generate_synth: bad range");
+    for (int i = 0; i < nframes; i++)
+    {
+        uint8_t *d = p->clip + p->frame_bytes*(size_t)(first + i);
+#ifdef H264E_EMU
+        for (int k = 0; k < (int)p->frame_bytes; k++) d[k] = sv_sample(p->G.width, p->G.height, t0 + i, seed, k);
+#else
+        HIPCHK(hipSetDevice(p->device));
+        hipLaunchKernelGGL(h264e_synth_kernel, dim3(1024), dim3(256), 0, p->stream, d, p->G.width, p->G.height, t0 + i, seed);
+#endif
+    }
+#ifndef H264E_EMU
+    HIPCHK(hipGetLastError());
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_sync(h264e_hip_pool_t *p)
+{
+    if (!p) FAIL("sync: null pool");
+#ifndef H264E_EMU
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    for (int i = 0; i < p->ev_pending; i++)
+    {
+        float a = 0, b = 0;
+        HIPCHK(hipEventElapsedTime(&a, p->ev[i][0], p->ev[i][1]));
+        HIPCHK(hipEventElapsedTime(&b, p->ev[i][1], p->ev[i][2]));
+        p->prof_mb_ms += a; p->prof_splice_ms += b; p->prof_launches++;
+    }
+    p->ev_pending = 0;
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, p->errflag, sizeof(int), hipMemcpyDeviceToHost));
+    if (err)
+    {
+        (void)hipMemset(p->errflag, 0, sizeof(int));
+        FAIL("macroblock kernel gave up waiting for the row above (bounded spin expired)");
+    }
+#endif
+    p->pending = 0;
+    return 0;
+}
+
+extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tasks)
+{
+    if (!p || !tasks) FAIL("submit: null argument");
+    const h264e_geom_t &G = p->G;
+    if (p->pending >= TASK_RING - 1 && h264e_hip_sync(p)) return -1;
+    h264e_frame_task_t *host = (h264e_frame_task_t *)calloc((size_t)p->nchains, sizeof(h264e_frame_task_t));
+    if (!host) FAIL("out of host memory");
+    int any = 0;
+    for (int c = 0; c < p->nchains; c++)
+    {
+        const h264e_hip_task_t &t = tasks[c];
+        h264e_frame_task_t &d = host[c];
+        d.active = t.active;
+        if (!t.active) continue;
+        if (t.frame_index < 0 || t.frame_index >= p->frames_resident || t.frame_slot < 0 || t.frame_slot >= p->slots ||
+            t.qp < 10 || t.qp > 51 || t.hdr_nbits < 8 || t.hdr_nbits > 64)
+        {
+            free(host);
+            FAIL("submit: bad task for chain %d", c);
+        }
+        any = 1;
+        const uint8_t *f = p->clip + p->frame_bytes*(size_t)t.frame_index;
+        d.in[0] = f; d.in[1] = f + (size_t)G.width*G.height; d.in[2] = d.in[1] + (size_t)(G.width/2)*(G.height/2);
+        d.in_stride[0] = G.width; d.in_stride[1] = d.in_stride[2] = G.width/2;
+        d.slice_type = t.slice_type; d.qp = t.qp; d.speed = t.speed;
+        d.no_deblock = (t.speed == 8 || t.speed == 10);                 /* h264-lab.h:6717 */
+        d.ref_sel = p->ref_sel[c];
+        d.frame_slot = t.frame_slot;
+        d.hdr_nbits = t.hdr_nbits; d.hdr_bits = t.hdr_bits;
+        d.clusters[0] = t.mv_clusters[0]; d.clusters[1] = t.mv_clusters[1];
+        d.clusters_per_mb = 0;
+        if (t.mv_clusters_per_mb)
+        {
+            const size_t n = sizeof(int32_t)*2*(size_t)G.nmb;
+            if (!p->clu_dev[c] && dev_malloc((void **)&p->clu_dev[c], n)) { free(host); FAIL("device allocation failed"); }
+#ifdef H264E_EMU
+            memcpy(p->clu_dev[c], t.mv_clusters_per_mb, n);
+#else
+            /* the re-encode path is rare and synchronous: a blocking copy keeps the host array's lifetime simple */
+            if (hipStreamSynchronize(p->stream) != hipSuccess || hipMemcpy(p->clu_dev[c], t.mv_clusters_per_mb, n, hipMemcpyHostToDevice) != hipSuccess)
+            {
+                free(host);
+                FAIL("mv_clusters upload failed");
+            }
+#endif
+            d.clusters_per_mb = p->clu_dev[c];
+        }
+        memcpy(d.qdat, t.qdat, sizeof(d.qdat));
+        p->ref_sel[c] ^= 1;
+    }
+    if (!any) { free(host); return 0; }
+    h264e_frame_task_t *slot = p->tasks_dev + (size_t)p->ring_pos*p->nchains;
+    p->ring_pos = (p->ring_pos + 1) % TASK_RING;
+    p->pending++;
+#ifdef H264E_EMU
+    memcpy(slot, host, sizeof(h264e_frame_task_t)*(size_t)p->nchains);
+    free(host);
+    for (int c = 0; c < p->nchains; c++)
+    {
+        const h264e_frame_task_t &T = slot[c];
+        if (!T.active) continue;
+        const h264e_chain_dev_t &C = p->chains_dev[c];
+        for (int row = 0; row < G.nmby; row++)
+        {
+            RowLds *L = (RowLds *)calloc(1, sizeof(RowLds));
+            row_begin(*L, G, C, T, row);
+            for (int x = 0; x < G.nmbx; x++) row_step(*L, G, C, T, row, x);
+            row_end(*L, G, C, row);
+            free(L);
+        }
+        finalize_frame(G, C, T);
+    }
+#else
+    HIPCHK(hipSetDevice(p->device));
+    /* pageable source: the runtime stages the copy before returning, so `host` can be freed right away */
+    hipError_t e = hipMemcpyAsync(slot, host, sizeof(h264e_frame_task_t)*(size_t)p->nchains, hipMemcpyHostToDevice, p->stream);
+    free(host);
+    if (e != hipSuccess) FAIL("task upload: %s", hipGetErrorString(e));
+    HIPCHK(hipMemsetAsync(p->progress_all, 0, sizeof(int)*(size_t)p->nchains*G.nmby, p->stream));
+    const int pe = p->ev_pending;
+    if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][0], p->stream));
+    hipLaunchKernelGGL(h264e_mb_kernel, dim3((unsigned)(p->nchains*G.nmby)), dim3(64), 0, p->stream,
+                       G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, p->nchains, p->errflag);
+    if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][1], p->stream));
+    hipLaunchKernelGGL(h264e_splice_kernel, dim3((unsigned)p->nchains), dim3(64), 0, p->stream,
+                       G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot);
+    HIPCHK(hipGetLastError());
+    if (p->profile)
+    {
+        HIPCHK(hipEventRecord(p->ev[pe][2], p->stream));
+        p->ev_pending++;
+    }
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_result(h264e_hip_pool_t *p, int chain, int slot, h264e_hip_result_t *res)
+{
+    if (!p || !res || chain < 0 || chain >= p->nchains || slot < 0 || slot >= p->slots) FAIL("result: bad argument");
+    h264e_frameout_t f;
+#ifdef H264E_EMU
+    f = p->chains_host[chain].fout[slot];
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpy(&f, p->chains_host[chain].fout + slot, sizeof(f), hipMemcpyDeviceToHost));
+#endif
+    res->nbytes = f.nbytes; res->all_skipped = f.all_skipped; res->clusters_moved = f.clusters_moved; res->overflow = f.overflow;
+    return 0;
+}
+
+extern "C" int h264e_hip_read_rbsp(h264e_hip_pool_t *p, int chain, int slot, uint8_t *dst, uint32_t cap)
+{
+    if (!p || !dst || chain < 0 || chain >= p->nchains || slot < 0 || slot >= p->slots) FAIL("read_rbsp: bad argument");
+    h264e_frameout_t f;
+#ifdef H264E_EMU
+    f = p->chains_host[chain].fout[slot];
+    if (f.nbytes > cap) FAIL("read_rbsp: destination too small");
+    memcpy(dst, p->chains_host[chain].arena + f.offset, f.nbytes);
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpy(&f, p->chains_host[chain].fout + slot, sizeof(f), hipMemcpyDeviceToHost));
+    if (f.nbytes > cap) FAIL("read_rbsp: destination too small");
+    HIPCHK(hipMemcpy(dst, p->chains_host[chain].arena + f.offset, f.nbytes, hipMemcpyDeviceToHost));
+#endif
+    return (int)f.nbytes;
+}
+
+extern "C" int h264e_hip_read_chain(h264e_hip_pool_t *p, int chain, int nslots, h264e_hip_result_t *res, uint32_t *offsets,
+                                    uint8_t *arena_dst, uint32_t cap, uint32_t *used)
+{
+    if (!p || !res || !offsets || !arena_dst || chain < 0 || chain >= p->nchains || nslots < 0 || nslots > p->slots) FAIL("read_chain: bad argument");
+    h264e_frameout_t *f = (h264e_frameout_t *)malloc(sizeof(h264e_frameout_t)*(size_t)(nslots ? nslots : 1));
+    uint32_t cur = 0;
+    if (!f) FAIL("out of host memory");
+#ifdef H264E_EMU
+    memcpy(f, p->chains_host[chain].fout, sizeof(h264e_frameout_t)*(size_t)nslots);
+    memcpy(&cur, p->chains_host[chain].cursor, 4);
+#else
+    if (hipSetDevice(p->device) != hipSuccess ||
+        hipMemcpy(f, p->chains_host[chain].fout, sizeof(h264e_frameout_t)*(size_t)nslots, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&cur, p->chains_host[chain].cursor, 4, hipMemcpyDeviceToHost) != hipSuccess)
+    {
+        free(f);
+        FAIL("read_chain: copy failed");
+    }
+#endif
+    for (int i = 0; i < nslots; i++)
+    {
+        res[i].nbytes = f[i].nbytes; res[i].all_skipped = f[i].all_skipped; res[i].clusters_moved = f[i].clusters_moved; res[i].overflow = f[i].overflow;
+        offsets[i] = f[i].offset;
+    }
+    free(f);
+    if (cur > cap) FAIL("read_chain: destination too small (%u > %u)", cur, cap);
+#ifdef H264E_EMU
+    memcpy(arena_dst, p->chains_host[chain].arena, cur);
+#else
+    HIPCHK(hipMemcpy(arena_dst, p->chains_host[chain].arena, cur, hipMemcpyDeviceToHost));
+#endif
+    if (used) *used = cur;
+    return 0;
+}
+
+extern "C" int h264e_hip_read_mbrec(h264e_hip_pool_t *p, int chain, int slot, h264e_hip_mbrec_t *dst)
+{
+    if (!p || !dst || chain < 0 || chain >= p->nchains || slot < 0 || slot >= p->slots) FAIL("read_mbrec: bad argument");
+    const size_t n = sizeof(h264e_mbrec_t)*(size_t)p->G.nmb;
+#ifdef H264E_EMU
+    memcpy(dst, p->chains_host[chain].mbrec + (size_t)slot*p->G.nmb, n);
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpy(dst, p->chains_host[chain].mbrec + (size_t)slot*p->G.nmb, n, hipMemcpyDeviceToHost));
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_read_recon(h264e_hip_pool_t *p, int chain, uint8_t *dst)
+{
+    if (!p || !dst || chain < 0 || chain >= p->nchains) FAIL("read_recon: bad argument");
+    const size_t n = (size_t)p->G.W*p->G.H*3/2;
+    const uint8_t *src = p->chains_host[chain].rec[p->ref_sel[chain]][0];   /* after the swap: last reconstruction */
+#ifdef H264E_EMU
+    memcpy(dst, src, n);
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_reset_results(h264e_hip_pool_t *p, int chain)
+{
+    if (!p || chain < 0 || chain >= p->nchains) FAIL("reset_results: bad argument");
+#ifdef H264E_EMU
+    memset(p->chains_host[chain].cursor, 0, 16);
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemsetAsync(p->chains_host[chain].cursor, 0, 16, p->stream));
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_rewind_frame(h264e_hip_pool_t *p, int chain)
+{
+    if (!p || chain < 0 || chain >= p->nchains) FAIL("rewind_frame: bad argument");
+    p->ref_sel[chain] ^= 1;
+    return 0;
+}
+
+extern "C" void h264e_hip_profile(h264e_hip_pool_t *p, int enable)
+{
+    if (!p) return;
+    p->profile = enable; p->prof_launches = 0; p->prof_mb_ms = p->prof_splice_ms = 0;
+}
+
+extern "C" int h264e_hip_profile_read(h264e_hip_pool_t *p, double *mb_ms, double *splice_ms, int *launches)
+{
+    if (!p) FAIL("profile_read: null pool");
+    if (mb_ms) *mb_ms = p->prof_mb_ms;
+    if (splice_ms) *splice_ms = p->prof_splice_ms;
+    if (launches) *launches = p->prof_launches;
+    return 0;
+}
+
+extern "C" int h264e_hip_timer_start(h264e_hip_pool_t *p)
+{
+    if (!p) FAIL("timer_start: null pool");
+#ifndef H264E_EMU
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipEventRecord(p->ev_t0, p->stream));
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_timer_stop(h264e_hip_pool_t *p, double *ms)
+{
+    if (!p || !ms) FAIL("timer_stop: null argument");
+    *ms = 0;
+#ifndef H264E_EMU
+    float f = 0;
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipEventRecord(p->ev_t1, p->stream));
+    HIPCHK(hipEventSynchronize(p->ev_t1));
+    HIPCHK(hipEventElapsedTime(&f, p->ev_t0, p->ev_t1));
+    *ms = f;
+#endif
+    return 0;
+}

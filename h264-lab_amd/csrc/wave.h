@@ -1,0 +1,109 @@
+/*
+ * wave.h -- the wave64 programming model the macroblock pipeline is written in.
+ *
+ * One workgroup = one 64-lane wavefront = one macroblock row.  The control flow of the
+ * encoder is WAVE-UNIFORM: every lane executes the same scalar decisions on the same values
+ * (registers replicated per lane, shared state in LDS), and pixel work fans out over the
+ * lanes inside WAVE_FOR sections.  Cross-lane traffic goes through LDS (followed by
+ * wave_sync()) or through the reductions below.
+ *
+ * Two builds of the same sources:
+ *   - hipcc --offload-arch=gfx950 : the product (h264e_kernels.hip).
+ *   - g++ -DH264E_EMU             : a lane-loop emulation used ONLY by tests/ to debug the
+ *     kernel logic on a machine without a GPU.  It is never linked into libh264e_mi355x.so.
+ */
+#ifndef H264E_WAVE_H
+#define H264E_WAVE_H
+
+#include <stdint.h>
+#include <string.h>
+
+#ifdef H264E_EMU
+#define DEV static inline
+#define DCONST static const
+#ifdef H264E_EMU_REVERSE      /* run lanes in the opposite order: catches code that leaks a lane-private value */
+#define WAVE_FOR(l) for (int l = 63; l >= 0; --l)
+#else
+#define WAVE_FOR(l) for (int l = 0; l < 64; ++l)
+#endif
+DEV void wave_sync() {}
+DEV int wave_lane() { return 0; }
+template <class F> DEV int wave_sum(F f)
+{
+    int s = 0;
+    for (int l = 0; l < 64; ++l) s += f(l);
+    return s;
+}
+/* four sums at once: f(lane, v[4]) */
+template <class F> DEV void wave_sum4(F f, int out[4])
+{
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (int l = 0; l < 64; ++l)
+    {
+        int v[4] = { 0, 0, 0, 0 };
+        f(l, v);
+        for (int k = 0; k < 4; ++k) out[k] += v[k];
+    }
+}
+template <class F> DEV uint64_t wave_ballot(F f)
+{
+    uint64_t m = 0;
+    for (int l = 0; l < 64; ++l) if (f(l)) m |= 1ull << l;
+    return m;
+}
+DEV uint32_t sad4_u8(uint32_t a, uint32_t b, uint32_t acc)
+{
+    for (int k = 0; k < 4; ++k)
+    {
+        int d = (int)((a >> (8*k)) & 255) - (int)((b >> (8*k)) & 255);
+        acc += (uint32_t)(d < 0 ? -d : d);
+    }
+    return acc;
+}
+DEV int clz32(uint32_t v) { return __builtin_clz(v); }
+DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+#else /* device build */
+
+#include <hip/hip_runtime.h>
+#define DEV static __device__ __forceinline__
+#define DCONST static __device__ const
+#define WAVE_FOR(l) for (int l = (int)threadIdx.x, _w1 = 1; _w1; _w1 = 0)
+/* single-wave workgroup: the barrier only orders this wave's LDS/global traffic for the compiler and the LDS queue */
+DEV void wave_sync() { __syncthreads(); }
+DEV int wave_lane() { return (int)threadIdx.x; }
+DEV int wave_reduce_add(int v)
+{
+    v += __shfl_xor(v, 32);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+template <class F> DEV int wave_sum(F f) { return wave_reduce_add(f((int)threadIdx.x)); }
+template <class F> DEV void wave_sum4(F f, int out[4])
+{
+    int v[4] = { 0, 0, 0, 0 };
+    f((int)threadIdx.x, v);
+    /* partial sums stay below 2^16 for every caller (<= 64 lanes x 4 x 255): reduce two per register */
+    int a = v[0] | (v[1] << 16), b = v[2] | (v[3] << 16);
+    a = wave_reduce_add(a);
+    b = wave_reduce_add(b);
+    out[0] = a & 0xffff; out[1] = (int)((unsigned)a >> 16);
+    out[2] = b & 0xffff; out[3] = (int)((unsigned)b >> 16);
+}
+template <class F> DEV uint64_t wave_ballot(F f) { return __ballot(f((int)threadIdx.x)); }
+DEV uint32_t sad4_u8(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
+DEV int clz32(uint32_t v) { return __clz((int)v); }
+DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+#endif
+
+DEV int imin(int a, int b) { return a < b ? a : b; }
+DEV int imax(int a, int b) { return a > b ? a : b; }
+DEV int iabs(int x) { return x < 0 ? -x : x; }
+DEV int clip255(int x) { return x < 0 ? 0 : x > 255 ? 255 : x; }
+DEV int clip3(int lo, int hi, int x) { return x < lo ? lo : x > hi ? hi : x; }
+
+#endif

@@ -1,0 +1,87 @@
+/*
+ * h264e_hip.h -- thin C ABI over the HIP kernels of the per-frame encode path (libh264e_mi355x.so).
+ *
+ * This is the device boundary the C host code (h264e_host.c: H264E_sizeof / H264E_init / H264E_encode,
+ * encode_app) sits on.  It replaces, for the macroblock loop, the reference's internal call
+ *     H264E_encode_one -> encode_slice -> mb_encode          (/root/reference/src/h264-lab.h:6477, :6409, :5724)
+ * i.e. everything the reference reaches through its function table h264e_* (h264-lab.h:3274-3364).
+ * Plain pointers and sizes only; no C++ or torch types.
+ *
+ * A POOL holds `nchains` independent encoder chains of one picture geometry on one GPU.  A chain is a
+ * sequential stream of frames (reference / reconstruction ping-pong); independent GOPs are run as
+ * separate chains in the same kernel launch.  One h264e_hip_submit() call encodes
+ * one frame of every active chain: the macroblock kernel (one wavefront per macroblock row) followed by
+ * the slice splice kernel.  Calls are asynchronous on the pool's stream until h264e_hip_sync().
+ */
+#ifndef H264E_HIP_H
+#define H264E_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct h264e_hip_pool h264e_hip_pool_t;
+
+/* one frame of one chain */
+typedef struct
+{
+    int active;                 /* 0: chain idles in this step */
+    int frame_index;            /* which resident input frame (see h264e_hip_upload_*) */
+    int frame_slot;             /* where the result goes: 0 .. slots_per_chain-1 */
+    int slice_type;             /* 0 = P, 2 = I   (h264-lab.h:3203-3204) */
+    int qp;                     /* frame QP, 10..51 */
+    int speed;                  /* H264E_run_param_t.encode_speed (h264-lab.h:181) */
+    int hdr_nbits;              /* NAL header byte + slice header bits (h264-lab.h:4182-4333), <= 64 */
+    uint64_t hdr_bits;          /* right-aligned */
+    int32_t mv_clusters[2];     /* speculated enc->mv_clusters for the whole frame (h264-lab.h:766) */
+    const int32_t *mv_clusters_per_mb;  /* optional HOST array [nmb][2]: exact per-macroblock values (re-encode path) */
+    uint16_t qdat[2][42];       /* quantizer tables of rc_set_qp (h264-lab.h:5839-5912) */
+} h264e_hip_task_t;
+
+typedef struct
+{
+    uint32_t nbytes;            /* RBSP bytes of the slice NAL (header byte included, no start code, no escapes) */
+    int all_skipped;            /* every macroblock was skipped (rc_frame_end's skip_flag, h264-lab.h:6596) */
+    int clusters_moved;         /* the speculated mv_clusters state is not a fixed point of this frame */
+    int overflow;               /* a bit buffer overflowed: the result is invalid */
+} h264e_hip_result_t;
+
+typedef struct { int32_t mv0; int8_t type; uint8_t used_cand; uint8_t pad[2]; } h264e_hip_mbrec_t;
+
+int  h264e_hip_device_count(void);
+/* frames_resident: input frames kept in HBM; slots_per_chain: results kept per chain between reads */
+int  h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int width, int height, int nchains,
+                           int frames_resident, int slots_per_chain);
+void h264e_hip_pool_destroy(h264e_hip_pool_t *pool);
+/* packed I420 frames (width*height*3/2 bytes each) from host memory into resident slots first.. */
+int  h264e_hip_upload_i420(h264e_hip_pool_t *pool, int first, int nframes, const uint8_t *host_i420);
+/* one frame from three planes with arbitrary strides (the H264E_io_yuv_t of the drop-in API) */
+int  h264e_hip_upload_planes(h264e_hip_pool_t *pool, int index, const uint8_t *const yuv[3], const int stride[3]);
+/* fill resident frames [first, first+n) with the synth_v1 test clip ON THE DEVICE (bench input, already in HBM) */
+int  h264e_hip_generate_synth(h264e_hip_pool_t *pool, int first, int nframes, int t0, uint32_t seed);
+int  h264e_hip_submit(h264e_hip_pool_t *pool, const h264e_hip_task_t *tasks /* [nchains] */);
+int  h264e_hip_sync(h264e_hip_pool_t *pool);
+int  h264e_hip_result(h264e_hip_pool_t *pool, int chain, int slot, h264e_hip_result_t *res);
+int  h264e_hip_read_rbsp(h264e_hip_pool_t *pool, int chain, int slot, uint8_t *dst, uint32_t cap);
+/* all results of a chain in two copies: per-slot result + byte offset into arena_dst, which receives the used part of the arena */
+int  h264e_hip_read_chain(h264e_hip_pool_t *pool, int chain, int nslots, h264e_hip_result_t *res, uint32_t *offsets,
+                          uint8_t *arena_dst, uint32_t cap, uint32_t *used);
+int  h264e_hip_read_mbrec(h264e_hip_pool_t *pool, int chain, int slot, h264e_hip_mbrec_t *dst /* [nmb] */);
+/* reconstructed picture of the chain's last frame, coded size, packed I420 */
+int  h264e_hip_read_recon(h264e_hip_pool_t *pool, int chain, uint8_t *dst);
+/* forget the results of a chain (arena cursor back to 0); the reference picture is kept */
+int  h264e_hip_reset_results(h264e_hip_pool_t *pool, int chain);
+/* undo the reference/reconstruction swap of the chain's last submitted frame (re-encode path) */
+int  h264e_hip_rewind_frame(h264e_hip_pool_t *pool, int chain);
+/* kernel timing on the pool's stream (HIP events around every macroblock-kernel launch) */
+void h264e_hip_profile(h264e_hip_pool_t *pool, int enable);
+int  h264e_hip_profile_read(h264e_hip_pool_t *pool, double *mb_kernel_ms, double *splice_kernel_ms, int *launches);
+/* wall clock of a region on the pool's stream, by HIP events */
+int  h264e_hip_timer_start(h264e_hip_pool_t *pool);
+int  h264e_hip_timer_stop(h264e_hip_pool_t *pool, double *ms);
+const char *h264e_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,146 @@
+/*
+ * h264e_mi355x.h -- the reference's public encoder API, served by the MI355X HIP path.
+ *
+ * Drop-in boundary: the four entry points and three structs below are what an application written
+ * against /root/reference/src/h264-lab.h:1-318 links to; layouts are ABI (x86-64 LP64, built with the
+ * reference's default H264E_SVC_API=1, H264E_MAX_THREADS=0: create 56 B, run 48 B, io_yuv 40 B).
+ *
+ *   H264E_sizeof          replaces h264-lab.h:6868-6892   (same sizes as the reference reports)
+ *   H264E_init            replaces h264-lab.h:6375-6407
+ *   H264E_encode          replaces h264-lab.h:6654-6861   (macroblock loop runs as HIP kernels, include/h264e_hip.h)
+ *   H264E_set_vbv_state   replaces h264-lab.h:6898-6913
+ *
+ * Scope: AVC baseline, key and P frames, one reference frame, single slice per frame,
+ * constant QP or frame-level rate control.  Long-term reference frame types, SVC layers, the temporal
+ * denoiser, MB-level rate control and NALU-size slicing answer H264E_STATUS_BAD_PARAMETER at init /
+ * H264E_STATUS_BAD_FRAME_TYPE at encode instead of silently producing a different stream.
+ * The encoder needs a HIP device: without one H264E_init fails (H264E_STATUS_BAD_ARGUMENT) -- there is
+ * no CPU fallback.
+ */
+#ifndef H264E_MI355X_H
+#define H264E_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* h264-lab.h:25-34 */
+#define H264E_STATUS_SUCCESS                0
+#define H264E_STATUS_BAD_ARGUMENT           1
+#define H264E_STATUS_BAD_PARAMETER          2
+#define H264E_STATUS_BAD_FRAME_TYPE         3
+#define H264E_STATUS_SIZE_NOT_MULTIPLE_16   4
+#define H264E_STATUS_SIZE_NOT_MULTIPLE_2    5
+#define H264E_STATUS_BAD_LUMA_ALIGN         6
+#define H264E_STATUS_BAD_LUMA_STRIDE        7
+#define H264E_STATUS_BAD_CHROMA_ALIGN       8
+#define H264E_STATUS_BAD_CHROMA_STRIDE      9
+
+/* h264-lab.h:63-70 */
+#define H264E_FRAME_TYPE_DEFAULT    0
+#define H264E_FRAME_TYPE_KEY        6
+#define H264E_FRAME_TYPE_I          5
+#define H264E_FRAME_TYPE_GOLDEN     4
+#define H264E_FRAME_TYPE_RECOVERY   3
+#define H264E_FRAME_TYPE_P          2
+#define H264E_FRAME_TYPE_DROPPABLE  1
+#define H264E_FRAME_TYPE_CUSTOM     99
+
+/* h264-lab.h:83-172 */
+typedef struct H264E_create_param_tag
+{
+    int width;
+    int height;
+    int gop;                                /* key frame period; 0 = only the first frame; 1 = all intra */
+    int vbv_size_bytes;                     /* selects the SPS level; VBV model for rate control */
+    int vbv_overflow_empty_frame_flag;
+    int vbv_underflow_stuffing_flag;
+    int fine_rate_control_flag;             /* MB-level rate control: not supported (must be 0) */
+    int const_input_flag;                   /* 0: the reconstruction is written back into the input planes */
+    int max_long_term_reference_frames;     /* must be 0 */
+    int enableNEON;                         /* ignored */
+    int temporal_denoise_flag;              /* must be 0 */
+    int sps_id;
+    int num_layers;                         /* SVC: must be 0 or 1 */
+    int inter_layer_pred_flag;
+} H264E_create_param_t;
+
+/* h264-lab.h:177-226 */
+typedef struct H264E_run_param_tag
+{
+    int encode_speed;
+    int frame_type;
+    int long_term_idx_use;
+    int long_term_idx_update;
+    int desired_frame_bytes;
+    int qp_min;
+    int qp_max;
+    int desired_nalu_bytes;                 /* must be 0 (one slice per frame) */
+    void (*nalu_callback)(const unsigned char *nalu_data, int sizeof_nalu_data, void *token);
+    void *nalu_callback_token;
+} H264E_run_param_t;
+
+/* h264-lab.h:231-237 */
+typedef struct H264E_io_yuv_tag
+{
+    unsigned char *yuv[3];
+    int stride[3];
+} H264E_io_yuv_t;
+
+typedef struct H264E_persist_tag H264E_persist_t;
+typedef struct H264E_scratch_tag H264E_scratch_t;
+
+int  H264E_sizeof(const H264E_create_param_t *param, int *sizeof_persist, int *sizeof_scratch);
+int  H264E_init(H264E_persist_t *enc, const H264E_create_param_t *param);
+int  H264E_encode(H264E_persist_t *enc, H264E_scratch_t *scratch, const H264E_run_param_t *run_param,
+                  H264E_io_yuv_t *frame, unsigned char **coded_data, int *sizeof_coded_data);
+void H264E_set_vbv_state(H264E_persist_t *enc, int vbv_size_bytes, int vbv_fullness_bytes);
+
+/* ---- extensions (not in the reference) ---------------------------------------------------------------- */
+
+/* The reference API has no destructor: device resources of an encoder are released when the
+ * same persist blob is initialised again, at process exit, or explicitly here. */
+void H264E_close(H264E_persist_t *enc);
+/* Select the HIP device used by subsequent H264E_init calls of this process (default 0 / $H264E_DEVICE). */
+void H264E_set_device(int device);
+/* Last device-side error text (empty when none). */
+const char *H264E_last_error(void);
+
+/* Whole-clip encode with independent GOPs run as parallel chains on one GPU:
+ * bit-identical to feeding the frames one by one to H264E_encode.  Constant QP only. */
+typedef struct
+{
+    int width, height, gop, qp, speed;
+    int vbv_size_bytes;                     /* SPS level only */
+    int device;
+    int max_chains;                         /* GOP chains in flight (0 = all GOPs of the clip) */
+    int first_idr_pic_id_state;             /* enc->next_idr_pic_id before the first frame (0 for a fresh stream) */
+    int32_t mv_clusters_in[2];              /* enc->mv_clusters before the first frame (0,0 for a fresh stream) */
+} H264E_clip_param_t;
+
+typedef struct
+{
+    double upload_ms, encode_ms, readback_ms, assemble_ms;      /* host wall clock of the phases */
+    double mb_kernel_ms, splice_kernel_ms;                      /* HIP-event time inside the kernels (when profiled) */
+    int kernel_launches;
+    int chains, rounds, reencoded_gops;
+    int32_t mv_clusters_out[2];
+    int next_idr_pic_id_state;
+} H264E_clip_stats_t;
+
+typedef struct H264E_clip_tag H264E_clip_t;
+/* Create a clip encoder for nframes resident frames. */
+int  H264E_clip_open(H264E_clip_t **clip, const H264E_clip_param_t *par, int nframes);
+/* Input: packed I420 frames from host memory, or the synth_v1 test clip generated in HBM. */
+int  H264E_clip_upload(H264E_clip_t *clip, int first, int nframes, const uint8_t *i420);
+int  H264E_clip_generate_synth(H264E_clip_t *clip, int first, int nframes, int t0, uint32_t seed);
+/* Encode all resident frames; out receives the Annex-B stream. profile != 0 adds per-kernel HIP-event timing. */
+int  H264E_clip_encode(H264E_clip_t *clip, uint8_t *out, size_t cap, size_t *out_bytes, int *frame_bytes /* [nframes] or NULL */,
+                       int profile, H264E_clip_stats_t *stats);
+void H264E_clip_close(H264E_clip_t *clip);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
