@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json: 1080p macroblocks/sec, achieved HBM GB/s vs peak.
+
+A step = one pass of the encode path over one batch: a synthetic 1920x1080 I420 clip of 600 frames (synth_v1,
+generated in HBM before the timed region), IPPP GOP 30, QP 26, speed 0 (BASELINE.json configs[2]); the 20 GOPs run
+as parallel chains on the GPU.  The timed region covers everything after the input is resident: all kernel launches,
+read-back of the coded slices, host NAL assembly into the final Annex-B stream.
+With --gpus N (launched by torch.distributed.run) every rank encodes its own clip on its own GPU: GOPs/clips are
+independent, no data-path collective (weak scaling); torch.distributed only provides the barrier and the max-reduce.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H, FRAMES, GOP, QP = 1920, 1080, 600, 30, 26
+NMB = ((W + 15) // 16) * ((H + 15) // 16)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic bytes per macroblock: input 384 B; P frames also read the co-located reference
+# (384 B); every frame writes 384 B of reconstruction
+BYTES_I, BYTES_P = 384 + 384, 768 + 384
+
+
+def cpu_baseline(sample_frames=60):
+    """the reference's own CPU path (oracle/_ref/encode_app_ref, gcc -O2, 1 thread) on the first frames of the same
+    clip; falls back to the oracle restatement when the compiled reference is not in the snapshot"""
+    import ctypes as C
+    import oracle_lib
+    if not os.path.exists(oracle_lib.LIB):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "all"], stdout=subprocess.DEVNULL)
+    lib = oracle_lib.lib()
+    with tempfile.TemporaryDirectory() as tmp:
+        yuv = os.path.join(tmp, "bench_%dx%d.yuv" % (W, H))
+        buf = (C.c_uint8 * (W * H * 3 // 2))()
+        with open(yuv, "wb") as f:
+            for t in range(sample_frames):
+                lib.synth_v1_frame(buf, W, H, t, 1)
+                f.write(bytes(buf))
+        out = os.path.join(tmp, "o.264")
+        if os.path.exists(oracle_lib.REF_APP):
+            kind, cmd = "reference", [oracle_lib.REF_APP, "--input", yuv, "--output", out, "--qp", str(QP), "--gop", str(GOP)]
+        else:
+            kind, cmd = "port", [os.path.join(ROOT, "oracle", "build", "oracle_app"), "--input", yuv, "--output", out, "--qp", str(QP), "--gop", str(GOP)]
+        t0 = time.time()
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+        dt = time.time() - t0
+        ref_bytes = open(out, "rb").read()
+    return {"value": sample_frames * NMB / dt, "unit": "macroblocks/s", "cores": 1, "kind": kind,
+            "sample": "first %d frames of the same 1080p synth_v1 clip, IPPP GOP %d QP %d, single thread, %.1f s" % (sample_frames, GOP, QP, dt)}, ref_bytes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=FRAMES, help=argparse.SUPPRESS)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from __graft_entry__ import _pkg
+    P = _pkg()
+    frames = a.frames
+    enc = P.ClipEncoder(W, H, frames, gop=GOP, qp=QP, speed=0, device=local_rank)
+    enc.generate_synth(0, frames, t0=rank * frames, seed=1)   # every rank its own clip (weak scaling)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out, sizes, st = enc.encode()
+    barrier()
+    t0 = time.time()
+    mb_ms = splice_ms = 0.0
+    launches = 0
+    for _ in range(a.steps):
+        out, sizes, st = enc.encode(profile=True)     # HIP events on the encoder's own stream, read after the step
+        mb_ms += st.mb_kernel_ms
+        splice_ms += st.splice_kernel_ms
+        launches += st.kernel_launches
+    barrier()
+    dt = time.time() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_mb = world * a.steps * frames * NMB
+        value = total_mb / dt
+        gops = (frames + GOP - 1) // GOP
+        # per launch: one frame of every chain (the I frame of each GOP in launch 0, P frames afterwards)
+        alg_bytes = a.steps * NMB * sum((BYTES_P if (f % GOP) else BYTES_I) for f in range(frames))
+        achieved = alg_bytes / (mb_ms * 1e-3) / 1e9 if mb_ms > 0 else 0.0
+        line = {
+            "metric": "1080p macroblocks/sec", "value": value, "unit": "macroblocks/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "synthetic 1920x1080 YUV420 %d frames IPPP GOP %d QP %d on 1xMI355X per rank (BASELINE configs[2])" % (frames, GOP, QP),
+                       "frames_per_step": frames, "gop_chains": gops, "fps": world * a.steps * frames / dt,
+                       "coded_bytes_per_step": len(out), "reencoded_gops": st.reencoded_gops},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "h264e_mb_kernel", "launches": launches, "avg_launch_ms": mb_ms / max(launches, 1),
+                         "bytes_per_launch": alg_bytes / max(launches, 1), "splice_kernel_ms_total": splice_ms},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                cb, ref_bytes = cpu_baseline()
+                line["cpu_baseline"] = cb
+                # parity gate: the timed stream must start with the reference's stream for the sample
+                k = sum(sizes[:60])
+                line["config"]["parity_vs_cpu_baseline_sample"] = bool(out[:k] == ref_bytes) if frames >= 60 else None
+            except Exception as e:  # the baseline is informational: never lose the GPU line over it
+                line["cpu_baseline"] = {"value": None, "unit": "macroblocks/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
+        print(json.dumps(line))
+    enc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

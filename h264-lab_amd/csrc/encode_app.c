@@ -1,0 +1,263 @@
+/*
+ * encode_app -- command-line encoder with the reference CLI's contract (/root/reference/src/minih264e_test.c,
+ * "T:n" below), running on the MI355X HIP path through the H264E_* API.
+ *
+ * Kept from the reference: options are matched by prefix (T:121-131); EVERY --long option
+ * consumes the following argv, flags included (T:212); -o / -i / -r short forms, -r overwriting the input name
+ * (T:213-215); an unknown --option prints an error and parsing goes on (T:187-191), a bare argument prints the
+ * error and exits 1 (T:219-223, T:476-477); picture size comes from the LAST WxH or size name inside the input
+ * file name, default 352x288 (T:256-329, T:483-485); defaults gop 20, qp 33 (T:10-17); --maxframes only matters
+ * when 0 (T:576); --kbps K -> desired_frame_bytes = K*1000/8/30, qp 10..50 (T:596-600); vbv_size_bytes = 12500
+ * (T:524); --psnr makes const_input_flag 0 and prints the reference's PSNR line (T:331-405, T:521);
+ * stdout carries "sizeof_persist = %d sizeof_scratch = %d" and, with --stats, "frame=%d, bytes=%d" (T:568, T:650).
+ * Not kept: --gen (libm-dependent synthetic input), --threads (multi-slice build option), --denoise.
+ *
+ * Extras (new option names, also argv-consuming): --device N; --clip 1 encodes the whole file through the
+ * GOP-parallel clip encoder (H264E_clip_*; same bitstream, constant QP only); --chains N bounds chains in flight.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/h264e_mi355x.h"
+
+static struct
+{
+    char input_file[1024], output_file[1024], recon_file[1024];
+    int have_input, have_output;
+    int gop, qp, kbps, max_frames, speed, stats, psnr, device, clip, chains;
+} cmd;
+
+static int starts(const char *pattern, const char *p) { return !strncmp(pattern, p, strlen(pattern)); }
+
+static void parse_long(const char *p, const char *val)
+{
+    const char *v = val ? val : "";
+    if (starts("gop", p)) cmd.gop = atoi(v);
+    else if (starts("qp", p)) cmd.qp = atoi(v);
+    else if (starts("kbps", p)) cmd.kbps = atoi(v);
+    else if (starts("maxframes", p)) cmd.max_frames = atoi(v);
+    else if (starts("speed", p)) cmd.speed = atoi(v);
+    else if (starts("stats", p)) cmd.stats = 1;
+    else if (starts("psnr", p)) cmd.psnr = 1;
+    else if (starts("output", p)) { snprintf(cmd.output_file, sizeof(cmd.output_file), "%s", v); cmd.have_output = 1; }
+    else if (starts("input", p)) { snprintf(cmd.input_file, sizeof(cmd.input_file), "%s", v); cmd.have_input = 1; }
+    else if (starts("recon", p)) snprintf(cmd.recon_file, sizeof(cmd.recon_file), "%s", v);
+    else if (starts("device", p)) cmd.device = atoi(v);
+    else if (starts("clip", p)) cmd.clip = atoi(v);
+    else if (starts("chains", p)) cmd.chains = atoi(v);
+    else printf("ERROR: Unknown option %s\n", p);
+}
+
+static int read_cmdline(int argc, char **argv)
+{
+    int i;
+    cmd.gop = 20; cmd.qp = 33; cmd.max_frames = 99999; cmd.device = -1;
+    for (i = 1; i < argc; i++)
+    {
+        const char *p = argv[i];
+        if (*p++ == '-')
+        {
+            const char *val = i + 1 < argc ? argv[i + 1] : NULL;
+            switch (*p)
+            {
+            case '-': parse_long(p + 1, val); i++; break;
+            case 'o': snprintf(cmd.output_file, sizeof(cmd.output_file), "%s", val ? val : ""); cmd.have_output = 1; i++; break;
+            case 'i':
+            case 'r': snprintf(cmd.input_file, sizeof(cmd.input_file), "%s", val ? val : ""); cmd.have_input = 1; i++; break;
+            default: break;
+            }
+        } else
+        {
+            printf("ERROR: Unknown option %s\n", p);
+            return 0;
+        }
+    }
+    if (!cmd.have_input)
+    {
+        printf("Usage:\n    encode_app [options] --input <input[frame_size].yuv> --output <output.264>\n"
+               "Frame size can be: WxH sqcif qvga svga 4vga sxga xga vga qcif 4cif\n"
+               "    4sif cif sif pal ntsc d1 16cif 16sif 720p 4SVGA 4XGA 16VGA 16VGA\n"
+               "Options (every --option takes a value):\n"
+               "    --input,  -i <f>  --output, -o <f>  --gop <n>  --qp <n>  --kbps <n>  --maxframes <n>\n"
+               "    --speed <n>  --stats x  --psnr x  --device <n>  --clip 1  --chains <n>\n");
+        return 0;
+    }
+    return 1;
+}
+
+/* T:256-329 guess_format_from_name: the last WxH or size name in the string wins */
+static void guess_format(const char *name, int *w, int *h)
+{
+    static const struct { const char *n; int w, h; } fmt[] = {
+        { "sqcif", 128, 96 }, { "qvga", 320, 240 }, { "svga", 800, 600 }, { "4vga", 1280, 960 }, { "sxga", 1280, 1024 },
+        { "xga", 1024, 768 }, { "vga", 640, 480 }, { "qcif", 176, 144 }, { "4cif", 704, 576 }, { "4sif", 704, 480 },
+        { "cif", 352, 288 }, { "sif", 352, 240 }, { "pal", 720, 576 }, { "ntsc", 720, 480 }, { "d1", 720, 480 },
+        { "16cif", 1408, 1152 }, { "16sif", 1408, 960 }, { "720p", 1280, 720 }, { "4SVGA", 1600, 1200 }, { "4XGA", 2048, 1536 },
+        { "16VGA", 2560, 1920 }, { "16VGA", 2560, 1920 } };
+    int i = (int)strlen(name), found = 0;
+    while (--i >= 0)
+    {
+        const char *p = name + i;
+        int prev = found;
+        unsigned k;
+        found = 0;
+        if (*p >= '0' && *p <= '9')
+        {
+            char *end;
+            int width = (int)strtoul(p, &end, 10);
+            if (width && (*end == 'x' || *end == 'X') && (end[1] >= '1' && end[1] <= '9'))
+            {
+                int height = (int)strtoul(end + 1, &end, 10);
+                if (height) { *w = width; *h = height; found = 1; }
+            }
+        }
+        for (k = 0; k < sizeof(fmt)/sizeof(fmt[0]); k++)
+            if (!strncmp(p, fmt[k].n, strlen(fmt[k].n))) { *w = fmt[k].w; *h = fmt[k].h; found = 1; }
+        if (!found && prev) return;
+    }
+}
+
+static struct { double noise[4], count[4], bytes; int frames; } g_psnr;
+
+static void psnr_add(const unsigned char *p0, const unsigned char *p1, int w, int h, int bytes)   /* T:355-374 */
+{
+    int i, k;
+    for (k = 0; k < 3; k++)
+    {
+        double s = 0;
+        for (i = 0; i < w*h; i++) { int d = *p0++ - *p1++; s += d*d; }
+        g_psnr.count[k] += w*h;
+        g_psnr.noise[k] += s;
+        if (!k) w >>= 1, h >>= 1;
+    }
+    g_psnr.frames++;
+    g_psnr.bytes += bytes;
+}
+
+static void psnr_print(void)                                                                       /* T:376-405 */
+{
+    double fps = 30, kbps = g_psnr.bytes*8./((double)g_psnr.frames/(fps))/1000;
+    double db = 10*log10(255.*255/(g_psnr.noise[0]/g_psnr.count[0]));
+    int i;
+    printf("%5.0f kbps@30fps  ", kbps);
+    for (i = 0; i < 3; i++)
+        printf(" %s=%.2f db ", i ? (i == 1 ? "UPSNR" : "VPSNR") : "YPSNR", 10*log10(255.*255/(g_psnr.noise[i]/g_psnr.count[i])));
+    printf("  %6.2f db/rate ", 10*log10((double)g_psnr.count[0]*g_psnr.count[0]*3/2*255*255/(g_psnr.noise[0]*g_psnr.bytes)));
+    printf("  %6.3f db/lgrate ", db/log10(kbps));
+    printf("  \n");
+}
+
+static int run_clip_mode(FILE *fin, FILE *fout, int w, int h)
+{
+    const size_t fsz = (size_t)w*h*3/2;
+    H264E_clip_param_t par;
+    H264E_clip_stats_t st;
+    H264E_clip_t *clip = NULL;
+    long total;
+    int n, i, *sizes;
+    uint8_t *buf, *out;
+    size_t nb = 0;
+    fseek(fin, 0, SEEK_END);
+    total = ftell(fin);
+    fseek(fin, 0, SEEK_SET);
+    n = (int)((size_t)total/fsz);
+    if (n <= 0) return 0;
+    memset(&par, 0, sizeof(par));
+    par.width = w; par.height = h; par.gop = cmd.gop; par.qp = cmd.qp; par.speed = cmd.speed; par.vbv_size_bytes = 100000/8;
+    par.device = cmd.device < 0 ? 0 : cmd.device; par.max_chains = cmd.chains;
+    buf = (uint8_t *)malloc(fsz*(size_t)n);
+    out = (uint8_t *)malloc(fsz*(size_t)n + (1 << 20));
+    sizes = (int *)malloc(sizeof(int)*(size_t)n);
+    if (!buf || !out || !sizes || fread(buf, fsz, (size_t)n, fin) != (size_t)n) { printf("ERROR: not enough memory / short read\n"); return 1; }
+    if (H264E_clip_open(&clip, &par, n) || H264E_clip_upload(clip, 0, n, buf) ||
+        H264E_clip_encode(clip, out, fsz*(size_t)n + (1 << 20), &nb, sizes, 0, &st))
+    {
+        printf("ERROR: %s\n", H264E_last_error());
+        return 1;
+    }
+    if (cmd.stats) for (i = 0; i < n; i++) printf("frame=%d, bytes=%d\n", i, sizes[i]);
+    if (!fwrite(out, nb, 1, fout)) printf("ERROR writing output file\n");
+    fprintf(stderr, "clip: %d frames, %d chains, %d rounds, %d re-encoded GOPs, encode %.1f ms\n", n, st.chains, st.rounds, st.reencoded_gops, st.encode_ms);
+    H264E_clip_close(clip);
+    free(buf); free(out); free(sizes);
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    H264E_create_param_t create_param;
+    H264E_run_param_t run_param;
+    H264E_io_yuv_t yuv;
+    H264E_persist_t *enc;
+    H264E_scratch_t *scratch;
+    FILE *fin, *fout;
+    uint8_t *buf_in, *buf_save, *coded_data;
+    int w = 352, h = 288, i, frames = 0, frame_size, sizeof_persist = 0, sizeof_scratch = 0, error, sizeof_coded_data;
+
+    if (!read_cmdline(argc, argv)) return 1;
+    guess_format(cmd.input_file, &w, &h);
+    fin = fopen(cmd.input_file, "rb");
+    if (!fin) { printf("ERROR: cant open input file %s\n", cmd.input_file); return 1; }
+    fout = fopen(cmd.have_output ? cmd.output_file : "out.264", "wb");
+    if (!fout) { printf("ERROR: cant open output file %s\n", cmd.output_file); return 1; }
+    if (cmd.device >= 0) H264E_set_device(cmd.device);
+
+    memset(&create_param, 0, sizeof(create_param));
+    memset(&run_param, 0, sizeof(run_param));
+    create_param.enableNEON = 1;
+    create_param.num_layers = 1;
+    create_param.gop = cmd.gop;
+    create_param.height = h;
+    create_param.width = w;
+    create_param.const_input_flag = cmd.psnr ? 0 : 1;
+    create_param.vbv_size_bytes = 100000/8;
+
+    error = H264E_sizeof(&create_param, &sizeof_persist, &sizeof_scratch);
+    if (error) { printf("H264E_init error = %d\n", error); return 0; }
+    printf("sizeof_persist = %d sizeof_scratch = %d\n", sizeof_persist, sizeof_scratch);
+
+    if (cmd.clip && !cmd.kbps && !cmd.psnr)
+    {
+        int r = run_clip_mode(fin, fout, w, h);
+        fclose(fin); fclose(fout);
+        return r;
+    }
+
+    frame_size = w*h*3/2;
+    buf_in = (uint8_t *)malloc((size_t)frame_size);
+    buf_save = (uint8_t *)malloc((size_t)frame_size);
+    enc = (H264E_persist_t *)malloc((size_t)sizeof_persist);
+    scratch = (H264E_scratch_t *)malloc((size_t)sizeof_scratch);
+    if (!buf_in || !buf_save || !enc || !scratch) { printf("ERROR: not enough memory\n"); return 1; }
+    error = H264E_init(enc, &create_param);
+    if (error) { printf("H264E_init error = %d (%s)\n", error, H264E_last_error()); return 1; }
+
+    for (i = 0; cmd.max_frames; i++)
+    {
+        if (!fread(buf_in, (size_t)frame_size, 1, fin)) break;
+        if (cmd.psnr) memcpy(buf_save, buf_in, (size_t)frame_size);
+        yuv.yuv[0] = buf_in; yuv.stride[0] = w;
+        yuv.yuv[1] = buf_in + w*h; yuv.stride[1] = w/2;
+        yuv.yuv[2] = buf_in + w*h*5/4; yuv.stride[2] = w/2;
+        run_param.frame_type = 0;
+        run_param.encode_speed = cmd.speed;
+        if (cmd.kbps)
+        {
+            run_param.desired_frame_bytes = cmd.kbps*1000/8/30;
+            run_param.qp_min = 10;
+            run_param.qp_max = 50;
+        } else
+            run_param.qp_min = run_param.qp_max = cmd.qp;
+        error = H264E_encode(enc, scratch, &run_param, &yuv, &coded_data, &sizeof_coded_data);
+        if (error) { printf("H264E_encode error = %d (%s)\n", error, H264E_last_error()); return 1; }
+        if (cmd.stats) printf("frame=%d, bytes=%d\n", frames++, sizeof_coded_data);
+        if (!fwrite(coded_data, (size_t)sizeof_coded_data, 1, fout)) { printf("ERROR writing output file\n"); break; }
+        if (cmd.psnr) psnr_add(buf_save, buf_in, w, h, sizeof_coded_data);
+    }
+    if (cmd.psnr) psnr_print();
+    H264E_close(enc);
+    free(enc); free(scratch); free(buf_in); free(buf_save);
+    fclose(fin); fclose(fout);
+    return 0;
+}

@@ -418,7 +418,7 @@ static int encode_frame_exact(h264e_hip_pool_t *pool, int nchains, int chain, h2
         }
         memcpy(used, traj, sizeof(int32_t)*2*(size_t)nmb);
         task->mv_clusters_per_mb = used;
-        if (h264e_hip_rewind_frame(pool, chain)) goto done;
+        if (h264e_hip_rewind_frame(pool, chain, task->frame_slot)) goto done;
     }
     if (passes) *passes = pass + 1;
 done:

@@ -578,10 +578,17 @@ extern "C" int h264e_hip_reset_results(h264e_hip_pool_t *p, int chain)
     return 0;
 }
 
-extern "C" int h264e_hip_rewind_frame(h264e_hip_pool_t *p, int chain)
+extern "C" int h264e_hip_rewind_frame(h264e_hip_pool_t *p, int chain, int slot)
 {
-    if (!p || chain < 0 || chain >= p->nchains) FAIL("rewind_frame: bad argument");
+    if (!p || chain < 0 || chain >= p->nchains || slot < 0 || slot >= p->slots) FAIL("rewind_frame: bad argument");
     p->ref_sel[chain] ^= 1;
+    /* the frame's result is dropped too: the arena cursor goes back to where that result starts */
+#ifdef H264E_EMU
+    *p->chains_host[chain].cursor = p->chains_host[chain].fout[slot].offset;
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpyAsync(p->chains_host[chain].cursor, &p->chains_host[chain].fout[slot].offset, sizeof(uint32_t), hipMemcpyDeviceToDevice, p->stream));
+#endif
     return 0;
 }
 

@@ -71,8 +71,9 @@ int  h264e_hip_read_mbrec(h264e_hip_pool_t *pool, int chain, int slot, h264e_hip
 int  h264e_hip_read_recon(h264e_hip_pool_t *pool, int chain, uint8_t *dst);
 /* forget the results of a chain (arena cursor back to 0); the reference picture is kept */
 int  h264e_hip_reset_results(h264e_hip_pool_t *pool, int chain);
-/* undo the reference/reconstruction swap of the chain's last submitted frame (re-encode path) */
-int  h264e_hip_rewind_frame(h264e_hip_pool_t *pool, int chain);
+/* drop the chain's last submitted frame (result in `slot`): undo the reference/reconstruction swap and give its
+ * arena space back, so the frame can be submitted again (re-encode path) */
+int  h264e_hip_rewind_frame(h264e_hip_pool_t *pool, int chain, int slot);
 /* kernel timing on the pool's stream (HIP events around every macroblock-kernel launch) */
 void h264e_hip_profile(h264e_hip_pool_t *pool, int enable);
 int  h264e_hip_profile_read(h264e_hip_pool_t *pool, double *mb_kernel_ms, double *splice_kernel_ms, int *launches);

@@ -1,0 +1,78 @@
+"""CPU: the HIP kernel sources, compiled as the test-only lane-loop emulation (tests/emu), against the oracle and
+the reference's golden vectors.  This checks kernel LOGIC without a GPU; the GPU tests check the real thing."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+import clips
+import oracle_lib
+import pkg
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _emu():
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
+
+
+def _flags(s):
+    t = s.split()
+    d = dict(zip(t[0::2], t[1::2]))
+    return dict(gop=int(d.get("--gop", 20)), qp=int(d.get("--qp", 33)), speed=int(d.get("--speed", 0)), kbps=int(d.get("--kbps", 0)))
+
+
+SMALL = [g for g in GOLDEN if g["w"] * g["h"] * g["frames"] <= 352 * 288 * 8]
+
+
+@pytest.mark.parametrize("g", SMALL, ids=lambda g: "%s_%dx%d_%s" % (g["clip"], g["w"], g["h"], g["flags"].replace(" ", "")))
+def test_emulated_kernels_match_reference_golden(g):
+    P = pkg.load_pkg()
+    c = clips.make(g["clip"], g["w"], g["h"], g["frames"])
+    e = P.Encoder(g["w"], g["h"], lib=pkg.EMU_LIB, **_flags(g["flags"]))
+    parts = [e.encode(c[t]) for t in range(g["frames"])]
+    e.close()
+    assert [len(p) for p in parts] == g["frame_bytes"]
+    assert hashlib.md5(b"".join(parts)).hexdigest() == g["md5"]
+
+
+@pytest.mark.parametrize("lib", [pkg.EMU_LIB, pkg.EMU_REV_LIB], ids=["lanes_up", "lanes_down"])
+def test_lane_order_independence(lib):
+    # a wave-uniform value leaking out of a WAVE_FOR section would make the two lane orders disagree
+    P = pkg.load_pkg()
+    w, h, n = 176, 144, 3
+    c = clips.noise(w, h, n)
+    want, _ = oracle_lib.encode_clip(c, w, h, gop=30, qp=28)
+    e = P.Encoder(w, h, gop=30, qp=28, lib=lib)
+    assert b"".join(e.encode(c[t]) for t in range(n)) == want
+
+
+@pytest.mark.parametrize("name,w,h,n,gop,qp,chains", [
+    ("synth", 176, 144, 10, 3, 26, 2), ("pan", 176, 144, 9, 3, 30, 0), ("pan", 352, 288, 6, 2, 26, 3), ("noise", 64, 48, 6, 2, 30, 0)])
+def test_gop_chains_and_cluster_speculation(name, w, h, n, gop, qp, chains):
+    """GOP-parallel clip encoder == sequential stream, including clips whose motion moves mv_clusters (re-encode path)"""
+    P = pkg.load_pkg()
+    c = clips.make(name, w, h, n)
+    want, sizes = oracle_lib.encode_clip(c, w, h, gop=gop, qp=qp)
+    ce = P.ClipEncoder(w, h, n, gop=gop, qp=qp, max_chains=chains, lib=pkg.EMU_LIB)
+    ce.upload(c)
+    out, fs, st = ce.encode()
+    ce.close()
+    assert out == want and fs == sizes
+    if name == "pan":
+        assert st.reencoded_gops > 0        # this clip is built to defeat the speculation
+
+
+def test_unsupported_options_are_refused():
+    P = pkg.load_pkg()
+    import ctypes as C
+    L = P.load(pkg.EMU_LIB)
+    buf = C.create_string_buffer(1 << 20)
+    for kw in (dict(max_long_term_reference_frames=1), dict(temporal_denoise_flag=1), dict(fine_rate_control_flag=1), dict(num_layers=2)):
+        cp = P.CreateParam(width=64, height=48, gop=2, const_input_flag=1, **kw)
+        assert L.H264E_init(buf, C.byref(cp)) == 2
+    assert L.H264E_init(None, None) == 1
