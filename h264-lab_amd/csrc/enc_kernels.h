@@ -100,25 +100,68 @@ DEV uint32_t ref_load4(const Plane &P, int x, int y)
 DEV uint32_t lds32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 DEV void lds32_store(uint8_t *p, uint32_t v) { memcpy(p, &v, 4); }
 
+/* 4 bytes at an arbitrary LDS byte address: two aligned dword reads + v_alignbyte */
+DEV uint32_t lds32u(const uint8_t *p)
+{
+#ifdef H264E_EMU
+    uint32_t v; memcpy(&v, p, 4); return v;
+#else
+    const uint32_t a = (uint32_t)(uintptr_t)p;
+    const uint32_t *q = (const uint32_t *)(p - (a & 3));
+    return __builtin_amdgcn_alignbyte(q[1], q[0], a & 3);
+#endif
+}
+
+/*
+ * Reference luma through an LDS-staged window: WIN_W x WIN_W samples around the current macroblock
+ * (WIN_M samples of margin on every side), loaded once per macroblock with clamped coordinates.
+ * Accesses outside the window (long vectors) fall back to HBM.
+ */
+#define WIN_M 24
+#define WIN_W 64
+#define WIN_STRIDE 68       /* 17 dwords: consecutive rows start on different LDS banks */
+struct RefView { Plane P; const uint8_t *win; int wx0, wy0; };
+
+DEV uint32_t rv_load4(const RefView &V, int x, int y)
+{
+    const int lx = x - V.wx0, ly = y - V.wy0;
+    if (V.win && (unsigned)lx <= (unsigned)(WIN_W - 4) && (unsigned)ly < (unsigned)WIN_W) return lds32u(V.win + ly*WIN_STRIDE + lx);
+    return ref_load4(V.P, x, y);
+}
+
+/* one lane per window row, 16 dword loads in flight per lane */
+DEV void wave_load_window(uint8_t *win, const Plane &P, int wx0, int wy0)
+{
+    WAVE_FOR(l)
+    {
+        uint32_t v[WIN_W/4];
+#pragma unroll
+        for (int g = 0; g < WIN_W/4; g++) v[g] = ref_load4(P, wx0 + 4*g, wy0 + l);
+#pragma unroll
+        for (int g = 0; g < WIN_W/4; g++) lds32_store(win + l*WIN_STRIDE + 4*g, v[g]);
+    }
+    wave_sync();
+}
+
 /* ------------------------------------------------------------------ SAD (H:2162-2192) */
 
 /* SAD of the w x h block at integer position (x0,y0) of R against LDS block b (stride 16).  4 samples per lane. */
-DEV int wave_sad_ref(const Plane &R, int x0, int y0, const uint8_t *b, int w, int h)
+DEV int wave_sad_ref(const RefView &R, int x0, int y0, const uint8_t *b, int w, int h)
 {
     const int g = w >> 2, n = g*h;
     return wave_sum([&](int l) -> int {
         if (l >= n) return 0;
         int r = l/g, c = l - r*g;
-        return (int)sad4_u8(ref_load4(R, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
+        return (int)sad4_u8(rv_load4(R, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
     });
 }
 
 /* 16x16 SAD with the four 8x8 quadrant sums (H:2178-2187) */
-DEV int wave_sad_ref_q(const Plane &R, int x0, int y0, const uint8_t *b, int sad4[4])
+DEV int wave_sad_ref_q(const RefView &R, int x0, int y0, const uint8_t *b, int sad4[4])
 {
     wave_sum4([&](int l, int *v) {
         int r = l >> 2, c = l & 3;
-        v[(r >> 3)*2 + (c >> 1)] = (int)sad4_u8(ref_load4(R, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
+        v[(r >> 3)*2 + (c >> 1)] = (int)sad4_u8(rv_load4(R, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
     }, sad4);
     return sad4[0] + sad4[1] + sad4[2] + sad4[3];
 }
@@ -149,60 +192,72 @@ DEV int tap6(int a, int b, int c, int d, int e, int f) { return a - 5*b + 20*c +
 /*
  * Standard H.264 quarter-sample luma interpolation (H:2079-2131) of the 4 samples starting at integer
  * position (x,y), fraction (fx,fy): half samples from the 6-tap filter, quarter samples as rounded
- * averages of the two nearest integer/half samples.
+ * averages of the two nearest integer/half samples.  Everything is unrolled over compile-time indices so
+ * the tap arrays live in registers; the position dispatch is wave-uniform.
  */
-DEV uint32_t interp_luma4(const Plane &R, int x, int y, int fx, int fy)
+DEV uint32_t interp_luma4(const RefView &R, int x, int y, int fx, int fy)
 {
-    if (!(fx | fy)) return ref_load4(R, x, y);
-    int th[6][4], cb[6][5];
-    const int r0 = fy ? 0 : 2, r1 = fy ? 5 : 2;
-    for (int r = r0; r <= r1; r++)
+    if (!(fx | fy)) return rv_load4(R, x, y);
+    const int pos = fx + 4*fy;
+    int A[4], B[4];
+    bool avg = true;
+    if (fy == 0)
     {
-        uint32_t a = ref_load4(R, x - 4, y + r - 2), b = ref_load4(R, x, y + r - 2), c = ref_load4(R, x + 4, y + r - 2);
+        const uint32_t a = rv_load4(R, x - 4, y), b = rv_load4(R, x, y), c = rv_load4(R, x + 4, y);
         int p[12];
-        for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) { p[k] = (int)((a >> (8*k)) & 255); p[4 + k] = (int)((b >> (8*k)) & 255); p[8 + k] = (int)((c >> (8*k)) & 255); }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
         {
-            p[k] = (int)((a >> (8*k)) & 255); p[4 + k] = (int)((b >> (8*k)) & 255); p[8 + k] = (int)((c >> (8*k)) & 255);
+            B[i] = clip255((tap6(p[i + 2], p[i + 3], p[i + 4], p[i + 5], p[i + 6], p[i + 7]) + 16) >> 5);
+            A[i] = pos == 3 ? p[5 + i] : p[4 + i];
         }
-        for (int i = 0; i < 4; i++) th[r][i] = tap6(p[i + 2], p[i + 3], p[i + 4], p[i + 5], p[i + 6], p[i + 7]);
-        for (int i = 0; i < 5; i++) cb[r][i] = p[4 + i];
+        if (pos == 2) avg = false;
+        if (!avg) { A[0] = B[0]; A[1] = B[1]; A[2] = B[2]; A[3] = B[3]; }
+    } else
+    {
+        const bool need_h = fx != 0;        /* horizontal taps (b, s, j) */
+        int th[6][4], cb[6][5];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+        {
+            const uint32_t b = rv_load4(R, x, y + r - 2);
+            uint32_t a = 0, c = 0;
+            if (need_h) { a = rv_load4(R, x - 4, y + r - 2); }
+            c = rv_load4(R, x + 4, y + r - 2);
+            int p[12];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { p[k] = (int)((a >> (8*k)) & 255); p[4 + k] = (int)((b >> (8*k)) & 255); p[8 + k] = (int)((c >> (8*k)) & 255); }
+#pragma unroll
+            for (int i = 0; i < 4; i++) th[r][i] = tap6(p[i + 2], p[i + 3], p[i + 4], p[i + 5], p[i + 6], p[i + 7]);
+#pragma unroll
+            for (int i = 0; i < 5; i++) cb[r][i] = p[4 + i];
+        }
+        const int vd = (fx == 3) ? 1 : 0;   /* vertical half sample m (column x+1) instead of h */
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const int hv = vd ? clip255((tap6(cb[0][i + 1], cb[1][i + 1], cb[2][i + 1], cb[3][i + 1], cb[4][i + 1], cb[5][i + 1]) + 16) >> 5)
+                              : clip255((tap6(cb[0][i], cb[1][i], cb[2][i], cb[3][i], cb[4][i], cb[5][i]) + 16) >> 5);
+            const int hd = clip255((tap6(th[0][i], th[1][i], th[2][i], th[3][i], th[4][i], th[5][i]) + 512) >> 10);
+            const int hh = clip255(((fy == 3 ? th[3][i] : th[2][i]) + 16) >> 5);    /* b (row y) or s (row y+1) */
+            const int g = fy == 3 ? cb[3][i] : cb[2][i];                         /* integer sample G or the one below */
+            if (fx == 0)      { A[i] = hv; B[i] = g; }                         /* d h n */
+            else if (fx == 2) { A[i] = hd; B[i] = hh; }                        /* f j q */
+            else if (fy == 2) { A[i] = hv; B[i] = hd; }                        /* i k */
+            else              { A[i] = hh; B[i] = hv; }                        /* e g p r */
+        }
+        if (fy == 2 && (fx == 0 || fx == 2)) avg = false;                      /* h, j */
     }
     uint32_t out = 0;
-    const int pos = fx + 4*fy;
-    for (int i = 0; i < 4; i++)
-    {
-        int v;
-#define HPH(r) clip255((th[r][i] + 16) >> 5)
-#define HPV(d) clip255((tap6(cb[0][i + d], cb[1][i + d], cb[2][i + d], cb[3][i + d], cb[4][i + d], cb[5][i + d]) + 16) >> 5)
-#define HPD()  clip255((tap6(th[0][i], th[1][i], th[2][i], th[3][i], th[4][i], th[5][i]) + 512) >> 10)
-        switch (pos)
-        {
-        case 1:  v = (cb[2][i] + HPH(2) + 1) >> 1; break;
-        case 2:  v = HPH(2); break;
-        case 3:  v = (cb[2][i + 1] + HPH(2) + 1) >> 1; break;
-        case 4:  v = (cb[2][i] + HPV(0) + 1) >> 1; break;
-        case 5:  v = (HPH(2) + HPV(0) + 1) >> 1; break;
-        case 6:  v = (HPH(2) + HPD() + 1) >> 1; break;
-        case 7:  v = (HPH(2) + HPV(1) + 1) >> 1; break;
-        case 8:  v = HPV(0); break;
-        case 9:  v = (HPV(0) + HPD() + 1) >> 1; break;
-        case 10: v = HPD(); break;
-        case 11: v = (HPV(1) + HPD() + 1) >> 1; break;
-        case 12: v = (cb[3][i] + HPV(0) + 1) >> 1; break;
-        case 13: v = (HPH(3) + HPV(0) + 1) >> 1; break;
-        case 14: v = (HPH(3) + HPD() + 1) >> 1; break;
-        default: v = (HPH(3) + HPV(1) + 1) >> 1; break;
-        }
-#undef HPH
-#undef HPV
-#undef HPD
-        out |= (uint32_t)v << (8*i);
-    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) out |= (uint32_t)(avg ? (A[i] + B[i] + 1) >> 1 : A[i]) << (8*i);
     return out;
 }
 
 /* H:4905-4910 interpolate_luma: w x h block whose top-left is (bx,by) + mv (absolute quarter-pel) -> LDS dst */
-DEV void wave_interp_luma(const Plane &R, int bx, int by, mv32 mv, int w, int h, uint8_t *dst)
+DEV void wave_interp_luma(const RefView &R, int bx, int by, mv32 mv, int w, int h, uint8_t *dst)
 {
     const int g = w >> 2, n = g*h, ix = bx + (mvx(mv) >> 2), iy = by + (mvy(mv) >> 2), fx = mvx(mv) & 3, fy = mvy(mv) & 3;
     WAVE_FOR(l)
@@ -334,90 +389,84 @@ DEV void wave_pred_chroma(uint8_t *dst, const uint8_t *left, const uint8_t *top,
 
 /*
  * One row (4 samples) of intra 4x4 prediction mode m (H.264 8.3.1.2; same samples as H:1834-1960).
- * E(i): edge sample i steps clockwise from the top-left corner (i > 0 top, i < 0 left).
+ * edge (LDS) holds the 13 neighbours along the block border: edge[4 + i] = sample i steps clockwise from the
+ * top-left corner (i = -4..-1 left column bottom-up, 0 corner, 1..8 top row incl. top-right).
  */
-DEV uint32_t i4_pred_row(int m, int y, const uint8_t *t, const uint8_t *lf, int tl, int dc)
+DEV uint32_t i4_pred_row(int m, int y, const uint8_t *edge, int dc, const uint16_t *lut /* LDS copy of k_i4_lut */)
 {
+    if (m == 2) return (uint32_t)dc*0x01010101u;
     uint32_t o = 0;
-#define E(i) ((i) == 0 ? tl : (i) > 0 ? (int)t[(i) - 1] : (int)lf[-(i) - 1])
+#pragma unroll
     for (int x = 0; x < 4; x++)
     {
-        int v, z, k;
-        switch (m)
-        {
-        case 0: v = t[x]; break;
-        case 1: v = lf[y]; break;
-        default:
-        case 2: v = dc; break;
-        case 3: v = (x + y == 6) ? (t[6] + 3*t[7] + 2) >> 2 : (t[x + y] + 2*t[x + y + 1] + t[x + y + 2] + 2) >> 2; break;
-        case 4: z = x - y; v = (E(z - 1) + 2*E(z) + E(z + 1) + 2) >> 2; break;
-        case 5: z = 2*x - y; k = x - (y >> 1);
-            if (z >= 0 && !(z & 1)) v = (E(k) + E(k + 1) + 1) >> 1;
-            else if (z >= 0)        v = (E(k - 1) + 2*E(k) + E(k + 1) + 2) >> 2;
-            else if (z == -1)       v = (E(-1) + 2*E(0) + E(1) + 2) >> 2;
-            else                    v = (E(-y) + 2*E(-(y - 1)) + E(-(y - 2)) + 2) >> 2;
-            break;
-        case 6: z = 2*y - x; k = y - (x >> 1);
-            if (z >= 0 && !(z & 1)) v = (E(-k) + E(-(k + 1)) + 1) >> 1;
-            else if (z >= 0)        v = (E(-(k - 1)) + 2*E(-k) + E(-(k + 1)) + 2) >> 2;
-            else if (z == -1)       v = (E(-1) + 2*E(0) + E(1) + 2) >> 2;
-            else                    v = (E(x) + 2*E(x - 1) + E(x - 2) + 2) >> 2;
-            break;
-        case 7: k = x + (y >> 1);
-            v = (y & 1) ? (t[k] + 2*t[k + 1] + t[k + 2] + 2) >> 2 : (t[k] + t[k + 1] + 1) >> 1; break;
-        case 8: z = x + 2*y; k = y + (x >> 1);
-            if (z > 5)       v = lf[3];
-            else if (z == 5) v = (lf[2] + 3*lf[3] + 2) >> 2;
-            else if (z & 1)  v = (lf[k] + 2*lf[k + 1] + lf[k + 2] + 2) >> 2;
-            else             v = (lf[k] + lf[k + 1] + 1) >> 1;
-            break;
-        }
+        const uint32_t e = lut[16*m + 4*y + x];
+        const int t = (int)(e & 3), a = edge[(e >> 2) & 15], b = edge[(e >> 6) & 15], c = edge[(e >> 10) & 15];
+        const int v = t == 0 ? (a + 2*b + c + 2) >> 2 : t == 1 ? (a + b + 1) >> 1 : t == 2 ? a : (a + 3*b + 2) >> 2;
         o |= (uint32_t)v << (8*x);
     }
-#undef E
     return o;
 }
 
 /*
- * H:1810-1962 h264e_intra_choose_4x4: all nine modes evaluated at once, lane = (mode slot, row).
- * Test order DC,V,DDL,VL,H,HU,DDR,HD,VR with a strict "<" keeps the reference's tie-breaks.
+ * H:1810-1962 h264e_intra_choose_4x4: all nine modes evaluated at once, lane = (mode slot, row), each lane
+ * predicts its row and takes its SAD.  Test order DC,V,DDL,VL,H,HU,DDR,HD,VR with a strict "<" keeps the
+ * reference's tie-breaks.  top8 / leftcol (stride lstride) / tl point into the LDS working picture.
  * in = input block (stride 16), pred = LDS output (stride 16); returns mode | cost << 4.
+ * scratch (LDS): edge[16] bytes, rows[36] dwords, rowsad[36] ints.
  */
-DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_t *top8, const uint8_t *left4, int tl,
-                       int mpred, int penalty, uint32_t *rows /* LDS [9][4] */)
+struct I4Scratch { uint8_t edge[16]; uint32_t rows[36]; int rowsad[36]; uint16_t lut[9*16]; };
+
+DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_t *top8, const uint8_t *leftcol, int lstride,
+                       int mpred, int penalty, I4Scratch &S)
 {
-    const int order[9] = { 2, 0, 3, 7, 1, 8, 4, 6, 5 };
-    uint8_t t[8], lf[4];
-    for (int k = 0; k < 8; k++) t[k] = (avail & AV_T) ? top8[(k > 3 && !(avail & AV_TR)) ? 3 : k] : 0;
-    for (int k = 0; k < 4; k++) lf[k] = left4[k];
-    const int dc = dc_pred((avail & AV_L) ? lf : 0, (avail & AV_T) ? t : 0, 2);
-    int sads[9];
     WAVE_FOR(l)
     {
-        int k = l >> 2, y = l & 3;
-        if (k < 9) rows[4*k + y] = i4_pred_row(order[k], y, t, lf, tl, dc);
+        if (l < 4) S.edge[3 - l] = leftcol[l*lstride];
+        else if (l == 4) S.edge[4] = top8[-1];
+        else if (l < 13)
+        {
+            int k = l - 5;
+            S.edge[5 + k] = top8[(k > 3 && !(avail & AV_TR)) ? 3 : k];
+        }
     }
     wave_sync();
+    int dc;
+    {
+        const uint32_t lw = lds32(S.edge), tw = lds32u(S.edge + 5);
+        const int sl = (int)((lw & 255) + ((lw >> 8) & 255) + ((lw >> 16) & 255) + (lw >> 24));
+        const int st = (int)((tw & 255) + ((tw >> 8) & 255) + ((tw >> 16) & 255) + (tw >> 24));
+        const int hl = (avail & AV_L) != 0, ht = (avail & AV_T) != 0;
+        dc = (hl && ht) ? (sl + st + 4) >> 3 : hl ? (sl + 2) >> 2 : ht ? (st + 2) >> 2 : 128;
+    }
+    WAVE_FOR(l)
+    {
+        const int k = l >> 2, y = l & 3;
+        if (k < 9)
+        {
+            const int m = k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 3 : k == 3 ? 7 : k == 4 ? 1 : k == 5 ? 8 : k == 6 ? 4 : k == 7 ? 6 : 5;
+            const uint32_t row = i4_pred_row(m, y, S.edge, dc, S.lut);
+            S.rows[l] = row;
+            S.rowsad[l] = (int)sad4_u8(lds32(in + 16*y), row, 0);
+        }
+    }
+    wave_sync();
+    const int have_t = (avail & AV_T) != 0, have_l = (avail & AV_L) != 0, have_all = (avail & (AV_T | AV_L | AV_TL)) == (AV_T | AV_L | AV_TL);
+    int best = 0, best_sad = 0;
+#pragma unroll
     for (int k = 0; k < 9; k++)
     {
-        int m = order[k];
-        if ((m == 0 || m == 3 || m == 7) && !(avail & AV_T)) { sads[k] = -1; continue; }
-        if ((m == 1 || m == 8) && !(avail & AV_L)) { sads[k] = -1; continue; }
-        if ((m == 4 || m == 5 || m == 6) && (avail & (AV_T | AV_L | AV_TL)) != (AV_T | AV_L | AV_TL)) { sads[k] = -1; continue; }
-        int s = 0;
-        for (int y = 0; y < 4; y++) s += (int)sad4_u8(lds32(in + 16*y), rows[4*k + y], 0);
-        sads[k] = s + (m != mpred ? penalty : 0);
+        const int m = k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 3 : k == 3 ? 7 : k == 4 ? 1 : k == 5 ? 8 : k == 6 ? 4 : k == 7 ? 6 : 5;
+        const int ok = k == 0 ? 1 : k <= 3 ? have_t : k <= 5 ? have_l : have_all;
+        const int sad = S.rowsad[4*k] + S.rowsad[4*k + 1] + S.rowsad[4*k + 2] + S.rowsad[4*k + 3] + (m != mpred ? penalty : 0);
+        if (ok && (k == 0 || sad < best_sad)) { best = k; best_sad = sad; }
     }
-    int best = 0;
-    for (int k = 1; k < 9; k++)
-        if (sads[k] >= 0 && sads[k] < sads[best]) best = k;
-    wave_sync();
     WAVE_FOR(l)
     {
-        if (l < 4) lds32_store(pred + 16*l, rows[4*best + l]);
+        if (l < 4) lds32_store(pred + 16*l, S.rows[4*best + l]);
     }
     wave_sync();
-    return order[best] + (sads[best] << 4);
+    const int bm = best == 0 ? 2 : best == 1 ? 0 : best == 2 ? 3 : best == 3 ? 7 : best == 4 ? 1 : best == 5 ? 8 : best == 6 ? 4 : best == 7 ? 6 : 5;
+    return bm + (best_sad << 4);
 }
 
 /* ------------------------------------------------------------------ transform / quant */
@@ -431,25 +480,30 @@ DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_
 DEV unsigned wave_xform_quant(const uint8_t *inp, const uint8_t *pred, int mode, qblk_t *q, int16_t *dc, const uint16_t *qdat)
 {
     const int n = mode >> 1, i0 = mode & 1, nb = n*n;
-    /* forward transform: coefficient (kh,kv) = sum_x sum_y Cf[kh][x]*Cf[kv][y]*r[y][x]; no rounding anywhere, so
-     * the matrix form equals the reference's butterflies (intermediates stay within int16) */
+    /* forward transform (H:2374-2409): every lane produces one coefficient (kh,kv) of its block: the four row
+     * butterflies, select output kh, then the column butterfly, select output kv.  No rounding anywhere and all
+     * intermediates fit int16, so this equals the reference's two-pass butterflies. */
     for (int pass = 0; pass*64 < nb*16; pass++)
     {
         WAVE_FOR(l)
         {
-            int idx = pass*64 + l, b = idx >> 4, i = idx & 15;
+            const int idx = pass*64 + l, b = idx >> 4, i = idx & 15;
             if (b < nb)
             {
-                const int cf[4][4] = { { 1, 1, 1, 1 }, { 2, 1, -1, -2 }, { 1, -1, -1, 1 }, { 1, -2, 2, -1 } };
-                int kh = i >> 2, kv = i & 3, bx = b % n, by = b / n, s = 0;
+                const int kh = i >> 2, kv = i & 3, bx = b % n, by = b / n;
                 const uint8_t *pi = inp + 64*by + 4*bx, *pp = pred + 64*by + 4*bx;
+                int rr[4];
+#pragma unroll
                 for (int y = 0; y < 4; y++)
                 {
-                    int rs = 0;
-                    for (int x = 0; x < 4; x++) rs += cf[kh][x]*((int)pi[16*y + x] - (int)pp[16*y + x]);
-                    s += cf[kv][y]*rs;
+                    const uint32_t a = lds32(pi + 16*y), c = lds32(pp + 16*y);
+                    const int d0 = (int)(a & 255) - (int)(c & 255), d1 = (int)((a >> 8) & 255) - (int)((c >> 8) & 255);
+                    const int d2 = (int)((a >> 16) & 255) - (int)((c >> 16) & 255), d3 = (int)(a >> 24) - (int)(c >> 24);
+                    const int t0 = d0 + d3, t1 = d0 - d3, t2 = d1 + d2, t3 = d1 - d2;
+                    rr[y] = kh == 0 ? t0 + t2 : kh == 1 ? 2*t1 + t3 : kh == 2 ? t0 - t2 : t1 - 2*t3;
                 }
-                q[b].dq[i] = (int16_t)s;
+                const int t0 = rr[0] + rr[3], t1 = rr[0] - rr[3], t2 = rr[1] + rr[2], t3 = rr[1] - rr[2];
+                q[b].dq[i] = (int16_t)(kv == 0 ? t0 + t2 : kv == 1 ? 2*t1 + t3 : kv == 2 ? t0 - t2 : t1 - 2*t3);
             }
         }
     }
@@ -619,35 +673,63 @@ DEV void wave_recon(uint8_t *out, int os, const uint8_t *pred, const qblk_t *q, 
 /* ------------------------------------------------------------------ CAVLC (uniform) */
 
 /*
- * H:2775-2949 h264e_vlc_encode.  coef[first .. first+maxn-1] scanned in decreasing index order;
- * nctx = left + top nnz context (NNZ_NA = 64 per unavailable side, 17+17 = chroma DC table).
- * Returns TotalCoeff.
+ * H:2775-2949 h264e_vlc_encode.  base[first .. first+maxn-1] (LDS, base 4-byte aligned) scanned in decreasing
+ * index order; nctx = left + top nnz context (NNZ_NA = 64 per unavailable side, 17+17 = chroma DC table).
+ * Works from the 16-bit mask of non-zero positions, so no per-lane arrays are needed.  Returns TotalCoeff.
  */
-DEV int cavlc_block(BitW &b, const int16_t *coef, int first, int maxn, int nctx)
+DEV int cavlc_block(BitW &b, const int16_t *base, int first, int maxn, int nctx)
 {
-    int lev[16], pos[16], total = 0, t1 = 0;
-    for (int i = maxn - 1; i >= 0; i--)
+    uint32_t mask = 0;
     {
-        int c = coef[first + i];
-        if (c) { lev[total] = c; pos[total] = i; total++; }
+        const uint32_t *w = (const uint32_t *)base;
+        const int nw = (first + maxn + 1) >> 1;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < nw)
+            {
+                const uint32_t v = w[k];
+                if (v & 0xffffu) mask |= 1u << (2*k);
+                if (v >> 16) mask |= 2u << (2*k);
+            }
+        mask = (mask >> first) & ((1u << maxn) - 1);
     }
-    while (t1 < 3 && t1 < total && (lev[t1] == 1 || lev[t1] == -1)) t1++;
+#ifdef H264E_EMU
+    const int total = __builtin_popcount(mask);
+#else
+    const int total = __popc(mask);
+#endif
+    /* trailing ones: up to three leading (highest position) coefficients of magnitude 1 */
+    int t1 = 0;
+    uint32_t t1sign = 0;
+    {
+        uint32_t m = mask;
+        while (m && t1 < 3)
+        {
+            const int p = 31 - clz32(m);
+            const int c = base[first + p];
+            if (c != 1 && c != -1) break;
+            t1sign = (t1sign << 1) | (uint32_t)(c < 0);
+            t1++;
+            m &= ~(1u << p);
+        }
+    }
     if (nctx <= 34) nctx = (nctx + 1) >> 1;
     nctx &= 31;
     const int tab = nctx < 2 ? 0 : nctx < 4 ? 1 : nctx < 8 ? 2 : nctx < 17 ? 3 : 4;
     bw_put(b, k_coeff_token[tab][total][t1][0], k_coeff_token[tab][total][t1][1]);
     if (!total) return 0;
-    if (t1)
+    if (t1) bw_put(b, t1, t1sign);
+    uint32_t m = mask;
+    for (int i = 0; i < t1; i++) m &= ~(1u << (31 - clz32(m)));
+    int sl = (total > 10 && t1 < 3) ? 1 : 0, firstlev = 1;
+    while (m)
     {
-        uint32_t s = 0;
-        for (int i = 0; i < t1; i++) s = (s << 1) | (uint32_t)(lev[i] < 0);
-        bw_put(b, t1, s);
-    }
-    int sl = (total > 10 && t1 < 3) ? 1 : 0;
-    for (int i = t1; i < total; i++)
-    {
-        int a = iabs(lev[i]), code = 2*a - 2 + (lev[i] < 0), prefix, nsuf, suf;
-        if (i == t1 && t1 < 3) code -= 2;
+        const int p = 31 - clz32(m);
+        m &= ~(1u << p);
+        const int lv = base[first + p], a = iabs(lv);
+        int code = 2*a - 2 + (lv < 0), prefix, nsuf, suf;
+        if (firstlev && t1 < 3) code -= 2;
+        firstlev = 0;
         if (sl == 0)
         {
             if (code < 14)      { prefix = code; nsuf = 0; suf = 0; }
@@ -665,14 +747,20 @@ DEV int cavlc_block(BitW &b, const int16_t *coef, int first, int maxn, int nctx)
     }
     if (total < maxn)
     {
-        int zeros = pos[0] + 1 - total;
+        const int top = 31 - clz32(mask);
+        int zeros = top + 1 - total;
         if (maxn == 4) bw_put(b, k_total_zeros_cdc[total - 1][zeros][0], k_total_zeros_cdc[total - 1][zeros][1]);
         else           bw_put(b, k_total_zeros[total - 1][zeros][0], k_total_zeros[total - 1][zeros][1]);
-        for (int k = 0; k < total - 1 && zeros > 0; k++)
+        uint32_t r = mask & ~(1u << top);
+        int prev = top;
+        while (r && zeros > 0)
         {
-            int run = pos[k] - pos[k + 1] - 1, zl = zeros > 7 ? 7 : zeros;
+            const int p = 31 - clz32(r);
+            r &= ~(1u << p);
+            const int run = prev - p - 1, zl = zeros > 7 ? 7 : zeros;
             bw_put(b, k_run_before[zl - 1][run][0], k_run_before[zl - 1][run][1]);
             zeros -= run;
+            prev = p;
         }
     }
     return total;

@@ -28,6 +28,7 @@ struct RowLds
     alignas(4) uint8_t strip_c[2][8*2];
     BitW bw;
     int skip_run, lead_skips, coded_any;
+    unsigned long long prof[32], prof_last;
 
     /* ---- per macroblock */
     mv32 mv_top[8];
@@ -39,7 +40,10 @@ struct RowLds
     mv32 mv[16], mvd[16], cand[20], part_mv[4][4], part_mvd[4][4], ctx_save[12];
     int8_t i4_mode[16];
     alignas(4) uint8_t bs[32];
-    uint32_t i4rows[36];
+    I4Scratch i4s;
+    uint8_t nzctx[12];
+    uint16_t qdat[2][42];                           /* this frame's quantizer tables, copied from the task */
+    alignas(16) uint8_t win[WIN_W*WIN_STRIDE + 16];  /* reference luma window around the current macroblock */
     alignas(16) uint8_t inp[256];
     alignas(16) uint8_t inp_c[128];
     alignas(16) uint8_t pred[256];
@@ -65,11 +69,13 @@ struct MbCtx
     const h264e_geom_t *G;
     const h264e_frame_task_t *T;
     Plane ref[3];
+    RefView rv;                                     /* reference luma through the LDS window */
     uint8_t *dec[3];
     int x, y, num, avail, type, cost, i16_mode, cropped, used_cand;
     mv32 mv_skip_pred;
     unsigned nz_mask;
     int qp;
+    int lambda_mv, lambda_q4, skip_thr, skip_thr_i4, lambda_i4, lambda_i16;     /* this QP's decision constants */
 };
 
 struct rect_t { int x0, y0, x1, y1; };
@@ -79,7 +85,7 @@ DEV mv32 clip_rect(mv32 v, const rect_t &r) { return mvmk(imin(imax(mvx(v), r.x0
 DEV mv32 mb_abs(const MbCtx &m, mv32 v) { return mvadd(v, mvmk(m.x*64, m.y*64)); }
 DEV int mv_cost(const MbCtx &m, mv32 v, mv32 pred)                                  /* H:4952 */
 {
-    return MUL_LAMBDA(se_len(mvx(v) - mvx(pred)) + se_len(mvy(v) - mvy(pred)), (int)k_lambda_mv_q4[m.qp]);
+    return MUL_LAMBDA(se_len(mvx(v) - mvx(pred)) + se_len(mvy(v) - mvy(pred)), m.lambda_mv);
 }
 DEV rect_t mv_limit(const MbCtx &m) { rect_t r = { m.G->lim_x0, m.G->lim_y0, m.G->lim_x1, m.G->lim_y1 }; return r; }
 DEV rect_t mv_qlimit(const MbCtx &m) { rect_t r = { m.G->lim_x0 + 16, m.G->lim_y0 + 16, m.G->lim_x1 - 16, m.G->lim_y1 - 16 }; return r; }
@@ -143,7 +149,7 @@ DEV mv32 mvp_get(const RowLds &L, const MbCtx &m, int x, int y, int w, int h)
         ret = mvmk(med3(mvx(a), mvx(b), mvx(c)), med3(mvy(a), mvy(b), mvy(c)));
     }
 #undef OK
-    return ret;
+    return (mv32)uni(ret);
 }
 
 /* ------------------------------------------------------------------ motion search */
@@ -167,30 +173,35 @@ DEV void set_range(mv32 &pnt, rect_t &range, const rect_t &limit, int mby_q)
  */
 DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_t &range, mv32 mv_pred, int min_sad, int w, int h)
 {
-    const int dxy[4][2] = { { 4, 0 }, { -4, 0 }, { 0, 4 }, { 0, -4 } };
-    const Plane &R = m.ref[0];
+    const RefView &R = m.rv;
     const uint8_t *b = L.inp + 16*py + px;
-    uint32_t cache[8];      /* values are uint16 */
+    /* the reference's uint16 cache[8]: four 16-bit fields each in `cur` (neighbours of the centre) and `prv` */
+    uint64_t cur, prv;
+#define CGET(c, d) ((uint32_t)((c) >> (16*(d))) & 0xffffu)
+#define CSET(c, d, v) c = ((c) & ~(0xffffull << (16*(d)))) | ((uint64_t)((v) & 0xffffu) << (16*(d)))
+#define DX(d) ((d) == 0 ? 4 : (d) == 1 ? -4 : 0)
+#define DY(d) ((d) == 2 ? 4 : (d) == 3 ? -4 : 0)
     int dir, cloop, dir_prev, cost;
     mv32 v;
+    mv = (mv32)uni(mv); mv_pred = (mv32)uni(mv_pred); min_sad = uni(min_sad);
     for (;;)
     {
         dir = 0; cloop = 4; dir_prev = -1;
-        for (int i = 0; i < 8; i++) cache[i] = 0xffff;
+        cur = prv = ~0ull;
         do
         {
-            v = mvadd(mv, mvmk(dxy[dir][0], dxy[dir][1]));
-            if (in_rect(v, range) && cache[dir] == 0xffffu)
+            v = mvadd(mv, mvmk(DX(dir), DY(dir)));
+            if (in_rect(v, range) && CGET(cur, dir) == 0xffffu)
             {
                 cost = wave_sad_ref(R, px + (mvx(v) >> 2), py + (mvy(v) >> 2), b, w, h) + mv_cost(m, v, mv_pred);
-                cache[dir] = (uint32_t)cost & 0xffff;
+                CSET(cur, dir, (uint32_t)cost);
                 if (cost < min_sad)
                 {
                     uint32_t corner = 0xffff;
-                    if (dir_prev >= 0) corner = cache[4 + dir];
-                    for (int i = 0; i < 4; i++) { cache[4 + i] = cache[i]; cache[i] = 0xffff; }
-                    if (dir_prev >= 0) cache[dir_prev ^ 1] = corner;
-                    cache[dir ^ 1] = (uint32_t)min_sad & 0xffff;
+                    if (dir_prev >= 0) corner = CGET(prv, dir);
+                    prv = cur; cur = ~0ull;
+                    if (dir_prev >= 0) CSET(cur, dir_prev ^ 1, corner);
+                    CSET(cur, dir ^ 1, (uint32_t)min_sad);
                     dir_prev = dir;
                     dir--;
                     cloop = 4 + 1;
@@ -201,8 +212,8 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
             dir = (dir + 1) & 3;
         } while (--cloop);
 
-        int pri = cache[3] >= cache[2] ? 2 : 3, sec = cache[1] >= cache[0] ? 0 : 1;
-        v = mvadd(mv, mvmk(dxy[pri][0] + dxy[sec][0], dxy[pri][1] + dxy[sec][1]));
+        const int pri = CGET(cur, 3) >= CGET(cur, 2) ? 2 : 3, sec = CGET(cur, 1) >= CGET(cur, 0) ? 0 : 1;
+        v = mvadd(mv, mvmk(DX(pri) + DX(sec), DY(pri) + DY(sec)));
         if (in_rect(v, range))
         {
             cost = wave_sad_ref(R, px + (mvx(v) >> 2), py + (mvy(v) >> 2), b, w, h) + mv_cost(m, v, mv_pred);
@@ -215,15 +226,21 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
         }
         break;
     }
+    const uint32_t c0 = CGET(cur, 0), c1 = CGET(cur, 1), c2 = CGET(cur, 2), c3 = CGET(cur, 3);
+#undef CGET
+#undef CSET
+#undef DX
+#undef DY
 
+    STAMP(L, 5);
     wave_interp_luma(R, px, py, mv, w, h, L.blk);
     if (m.T->speed < 9 && in_rect(mv, mv_qlimit(m)))
     {
         mv32 vbest = mv, pq = mvmk(0, -1), sq = mvmk(-1, 0);
-        uint32_t ms1 = cache[1], ms2 = cache[3];
+        uint32_t ms1 = c1, ms2 = c3;
         wave_copy_wh(L.p00, L.blk, w, h);
-        if (cache[3] >= cache[2]) { pq = mvmk(0, 1); ms2 = cache[2]; }
-        if (cache[1] >= cache[0]) { sq = mvmk(1, 0); ms1 = cache[0]; }
+        if (c3 >= c2) { pq = mvmk(0, 1); ms2 = c2; }
+        if (c1 >= c0) { sq = mvmk(1, 0); ms1 = c0; }
         if (ms2 > ms1) { mv32 s = sq; sq = pq; pq = s; }
         const mv32 vd = mvadd(pq, sq);
         for (int i = 0; i < 7; i++)
@@ -249,6 +266,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
         }
         mv = vbest;
     }
+    STAMP(L, 6);
     return min_sad;
 }
 
@@ -289,7 +307,7 @@ DEV void predict_chroma_inter(RowLds &L, const MbCtx &m)
  */
 DEV int skip_chroma_ok(const RowLds &L, const MbCtx &m)
 {
-    const int thr = k_skip_thr_inter[m.qp];
+    const int thr = m.skip_thr;
     for (int c = 0; c < 2; c++)
     {
         int sad = wave_sum([&](int l) -> int {
@@ -307,9 +325,8 @@ DEV int skip_chroma_ok(const RowLds &L, const MbCtx &m)
 /* H:5283-5524 inter_choose_mode */
 DEV void inter_choose(RowLds &L, MbCtx &m)
 {
-    const int nbits[4] = { 1, 4, 4, 12 };
-    int prefer[4] = { 1, 0, 0, 0 };
-    const Plane &R = m.ref[0];
+    int prefer[4] = { 1, 0, 0, 0 };      /* constant indices only after unrolling: stays in registers */
+    const RefView &R = m.rv;
     const int bx = m.x*16, by = m.y*16;
     int sad, sad_skip = 0x7FFFFFFF, sad_best = 0x7FFFFFFF, cand_cost_best = 0, j = 0, ncand = 0, sad4[4];
     mv32 mv_best = MV_NA;
@@ -326,11 +343,12 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
         L.df_mv[i] = L.mv_top[i];
     }
 
+    STAMP(L, 2);
     if (in_rect(mv_skip_a, mv_qlimit(m)))
     {
         wave_interp_luma(R, 0, 0, mv_skip_a, 16, 16, L.skip_pred);
         sad_skip = wave_sad_lds_q(L.inp, L.skip_pred, sad4);
-        if (imax(imax(sad4[0], sad4[1]), imax(sad4[2], sad4[3])) < (int)k_skip_thr_inter[m.qp])
+        if (imax(imax(sad4[0], sad4[1]), imax(sad4[2], sad4[3])) < m.skip_thr)
         {
             m.type = -1;
             L.mv[0] = mv_skip;
@@ -352,6 +370,7 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
         }
     }
 
+    STAMP(L, 3);
     m.used_cand = 1;
     L.cand[ncand++] = mv_pred16;
     L.cand[ncand++] = 0;                                                    /* H:3895-3914 */
@@ -397,6 +416,7 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
         }
     }
     sad_best += mv_cost(m, mv_best, mv_pred16);
+    STAMP(L, 4);
 
     /* H:3646-3671: every partitioning is tried from the same predictor state */
     for (int i = 0; i < 4; i++) { L.ctx_save[i] = L.mv_left[i]; L.ctx_save[4 + i] = L.mv_tl[i]; L.ctx_save[8 + i] = L.mv_top[i]; }
@@ -404,10 +424,10 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
     int best_n = 0;
     for (int t = 0; t < 4; t++)
     {
-        int imv = 0, part_sad = MUL_LAMBDA(nbits[t], (int)k_lambda_q4[m.qp]);
+        int imv = 0, part_sad = MUL_LAMBDA(t == 0 ? 1 : t == 3 ? 12 : 4, m.lambda_q4);
         const int w = (t & 2) ? 8 : 16, h = (t & 1) ? 8 : 16;
         int px = 0, py = 0;
-        if (!prefer[t]) continue;
+        if (!(t == 0 ? prefer[0] : t == 1 ? prefer[1] : t == 2 ? prefer[2] : prefer[3])) continue;
         for (;;)
         {
             rect_t range;
@@ -463,9 +483,8 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
 /* H:4838-4858 intra_estimate_16x16 + H:4876-4896 intra_choose_16x16 */
 DEV void intra16_choose(RowLds &L, MbCtx &m, const uint8_t *left, const uint8_t *top)
 {
-    const uint8_t valid[8] = { 4, 5, 6, 7, 4, 5, 6, 15 };
     const uint8_t *p = L.inp;
-    const int v = valid[m.avail & 7];
+    const int v = m.avail & 3;             /* H:4840 mode_i16x16_valid: bit 0 = vertical allowed (top), bit 1 = horizontal (left) */
     int mode, sad4[4];
     int dx = iabs(p[0] - p[15]) + iabs(p[15*16] - p[15*16 + 15]) + iabs(p[8*16] - p[8*16 + 15]);
     int dy = iabs(p[0] - p[15*16]) + iabs(p[15] - p[15*16 + 15]) + iabs(p[8] - p[15*16 + 8]);
@@ -474,7 +493,7 @@ DEV void intra16_choose(RowLds &L, MbCtx &m, const uint8_t *left, const uint8_t 
     else mode = 2;
     m.i16_mode = mode;
     wave_pred16(L.test, left, top, mode);
-    int sad = wave_sad_lds_q(L.inp, L.test, sad4) + MUL_LAMBDA(ue_len((uint32_t)mode + 1), (int)k_lambda_q4[m.qp]) + (int)k_lambda_i16_q4[m.qp];
+    int sad = wave_sad_lds_q(L.inp, L.test, sad4) + MUL_LAMBDA(ue_len((uint32_t)mode + 1), m.lambda_q4) + m.lambda_i16;
     if (sad < m.cost)
     {
         m.cost = sad;
@@ -486,10 +505,12 @@ DEV void intra16_choose(RowLds &L, MbCtx &m, const uint8_t *left, const uint8_t 
 /* H:4723-4833 intra_choose_4x4: 16 blocks in raster order, each predicted from reconstructed neighbours */
 DEV void intra4_choose(RowLds &L, MbCtx &m)
 {
-    const uint8_t block2avail[16] = { 0x07, 0x23, 0x23, 0x2b, 0x9b, 0x77, 0xff, 0x77, 0x9b, 0xff, 0xff, 0x77, 0x9b, 0x77, 0xff, 0x77 };
+    /* H:4750-4752 block2avail {07 23 23 2b 9b 77 ff 77 9b ff ff 77 9b 77 ff 77}: low nibble = mask on the macroblock's
+     * flags, high nibble = flags forced on; one byte per block, packed so the lookup needs no memory */
+    const uint64_t b2a_lo = 0x77ff779b2b232307ull, b2a_hi = 0x77ff779b77ffff9bull;
     uint8_t *r0 = L.i4rec + 24 + 4;       /* sample (0,0); row stride 24, 4 spare columns on the left keep rows 4-byte aligned */
     const int avail = m.avail;
-    int cost = k_lambda_i4_q4[m.qp];
+    int cost = m.lambda_i4;
     unsigned nz_mask = 0;
     WAVE_FOR(l)
     {
@@ -504,22 +525,21 @@ DEV void intra4_choose(RowLds &L, MbCtx &m)
         uint8_t *blk = r0 + 24*4*r + 4*c;
         const uint8_t *bin = L.inp + (c + r*16)*4;
         uint8_t *pr = L.tt;                                     /* prediction / reconstruction of this block, stride 16 */
-        int a = (avail & block2avail[n]) | (block2avail[n] >> 4);
-        if (!(block2avail[n] & AV_TL))
+        const int b2a = (int)(((n < 8 ? b2a_lo : b2a_hi) >> (8*(n & 7))) & 0xff);
+        int a = (avail & b2a) | (b2a >> 4);
+        if (!(b2a & AV_TL))
             if ((n <= 3 && (avail & AV_T)) || (n > 3 && (avail & AV_L))) a |= AV_TL;
         if (n < 3 && (avail & AV_T)) a |= AV_TR;
         int mpred = imin(L.i4_left[r], L.i4_top[c]);
         if (mpred < 0) mpred = 2;
-        uint8_t left4[4];
-        for (int i = 0; i < 4; i++) left4[i] = blk[24*i - 1];
-        int res = wave_i4_choose(bin, pr, a, blk - 24, left4, blk[-24 - 1], mpred, MUL_LAMBDA(3, (int)k_lambda_q4[m.qp]), L.i4rows);
+        int res = wave_i4_choose(bin, pr, a, blk - 24, blk - 1, 24, mpred, MUL_LAMBDA(3, m.lambda_q4), L.i4s);
         const int mode = res & 15, sad = res >> 4;
         L.i4_left[r] = L.i4_top[c] = (int8_t)mode;
         L.i4_mode[n] = (int8_t)(mode == mpred ? -1 : mode > mpred ? mode - 1 : mode);
         unsigned coded = 0;
-        if (sad > (int)k_skip_thr_i4x4[m.qp])
+        if (sad > m.skip_thr_i4)
         {
-            coded = wave_xform_quant(bin, pr, QMODE_I4, L.qy + n, (int16_t *)0, m.T->qdat[0]);
+            coded = wave_xform_quant(bin, pr, QMODE_I4, L.qy + n, (int16_t *)0, L.qdat[0]);
             if (coded) wave_recon(pr, 16, pr, L.qy + n, 1, 0x80000000u);
         } else
         {
@@ -544,10 +564,10 @@ DEV void intra4_choose(RowLds &L, MbCtx &m)
 /* H:4378-4715 mb_write.  Reconstruction goes to the LDS deblock tiles; bits to the row buffer. */
 DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
 {
-    const uint8_t scan8[16] = { 0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15 };         /* H:920 */
+#define SCAN8(i) ((((i) >> 3) & 1)*8 + (((i) >> 1) & 1)*4 + (((i) >> 2) & 1)*2 + ((i) & 1))     /* H:920 decode_block_scan */
     const int i16 = m.type >= 6;
     int cbpl = 0, cbpc = 0, cbp = 0;
-    uint8_t nz[9];
+    uint8_t *nz = L.nzctx;               /* nz[9]: the diagonal nnz context of H:4385-4401, in LDS (indexed dynamically) */
     uint8_t *ty = L.ytile + 4*YT_STRIDE + 4;
     uint8_t *tc[2] = { L.ctile[0] + 2*CT_STRIDE + 2, L.ctile[1] + 2*CT_STRIDE + 2 };
 
@@ -568,11 +588,11 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
     {
         if (m.type != 5)
         {
-            unsigned mask = wave_xform_quant(L.inp, L.pred, i16 ? QMODE_I16 : QMODE_INTER, L.qy, L.dcy, m.T->qdat[0]);
+            unsigned mask = wave_xform_quant(L.inp, L.pred, i16 ? QMODE_I16 : QMODE_INTER, L.qy, L.dcy, L.qdat[0]);
             m.nz_mask = mask & 0xffff;
             if (i16)
             {
-                quant_luma_dc(L.qy, L.dcy, L.lev_dcy, m.T->qdat[0]);
+                quant_luma_dc(L.qy, L.dcy, L.lev_dcy, L.qdat[0]);
                 mask = 0xFFFF;
             }
             wave_recon(ty, YT_STRIDE, L.pred, L.qy, 4, mask << 16);
@@ -594,9 +614,9 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
         {
             qblk_t *q = c ? L.qv : L.qu;
             int16_t *dc = c ? L.dcv : L.dcu;
-            unsigned mask = wave_xform_quant(L.inp_c + 8*c, L.pred_c + 8*c, QMODE_CHROMA, q, dc, m.T->qdat[1]);
+            unsigned mask = wave_xform_quant(L.inp_c + 8*c, L.pred_c + 8*c, QMODE_CHROMA, q, dc, L.qdat[1]);
             if (mask) cbpc = 2;
-            const int dc_flag = quant_chroma_dc(q, dc, c ? L.lev_dcv : L.lev_dcu, m.T->qdat[1]);
+            const int dc_flag = quant_chroma_dc(q, dc, c ? L.lev_dcv : L.lev_dcu, L.qdat[1]);
             cbpc |= dc_flag;
             if (dc_flag)
             {
@@ -656,7 +676,7 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
             if (m.type == 5)
                 for (int i = 0; i < 16; i++)
                 {
-                    int md = L.i4_mode[scan8[i]];
+                    int md = L.i4_mode[SCAN8(i)];
                     if (md < 0) bw_put(b, 1, 1); else bw_put(b, 4, (uint32_t)md);
                 }
             int cm = m.i16_mode;
@@ -690,7 +710,7 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
         {
             for (int i = 0; i < 16; i++)
             {
-                const int j = scan8[i], k = 4 + (j & 3) - (j >> 2);
+                const int j = SCAN8(i), k = 4 + (j & 3) - (j >> 2);
                 if (cbp & (1 << (i >> 2)))
                 {
                     nz[k] = (uint8_t)cavlc_block(b, L.qy[j].qv, i16, 16 - i16, nz[k - 1] + nz[k + 1]);
@@ -711,7 +731,7 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
             if (cbpc > 1)
                 for (int c = 0; c < 2; c++)
                 {
-                    uint8_t nzc[5];
+                    uint8_t *nzc = L.nzctx + 4;              /* nzc[5] aliases nz[4..8]: luma contexts are already stored back */
                     const int off = c ? 6 : 4;
                     const qblk_t *q = c ? L.qv : L.qu;
                     nzc[2] = 0;
@@ -736,6 +756,7 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
             for (int i = 4; i < 8; i++) L.nnz_top[i] = L.nnz_left[i] = 0;
     }
     wave_sync();
+#undef SCAN8
 }
 
 /* ------------------------------------------------------------------ deblock strengths */

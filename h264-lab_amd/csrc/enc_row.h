@@ -30,7 +30,16 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C,
     L.bw.cap = (uint32_t)G.row_words;
     L.bw.buf = C.rowbits + (size_t)row*G.row_words;
     L.skip_run = 0; L.lead_skips = 0; L.coded_any = 0;
+    WAVE_FOR(l)
+    {
+        for (int k = l; k < 84; k += 64) L.qdat[k/42][k%42] = T.qdat[k/42][k%42];
+        for (int k = l; k < 144; k += 64) L.i4s.lut[k] = k_i4_lut[k/16][k%16];
+    }
+    for (int i = 0; i < 32; i++) L.prof[i] = 0;
+    L.prof_last = 0;
     wave_sync();
+    STAMP(L, 31);
+    L.prof[31] = 0;
 }
 
 /* neighbour record of the macroblock above -> LDS (h264-lab.h:742-745 contexts, :590-606 deblock state) */
@@ -102,26 +111,41 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
     m.cropped = G.cropping && ((x + 1)*16 > G.width || (row + 1)*16 > G.height);
     m.type = 0; m.cost = 0x7FFFFFFF; m.i16_mode = 0; m.used_cand = 0; m.mv_skip_pred = 0; m.nz_mask = 0;
     m.qp = T.qp;
+    m.lambda_mv = uni((int)k_lambda_mv_q4[T.qp]); m.lambda_q4 = uni((int)k_lambda_q4[T.qp]); m.skip_thr = uni((int)k_skip_thr_inter[T.qp]);
+    m.skip_thr_i4 = uni((int)k_skip_thr_i4x4[T.qp]); m.lambda_i4 = uni((int)k_lambda_i4_q4[T.qp]); m.lambda_i16 = uni((int)k_lambda_i16_q4[T.qp]);
 
     h264e_mbbottom_t *rowrec = C.bottom + (size_t)row*G.nmbx;
+    STAMP(L, 0);
     load_top(L, G, rowrec - G.nmbx, x, row > 0);
     load_input(L, G, T, x, row);
+    m.rv.P = m.ref[0]; m.rv.win = (const uint8_t *)0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
+    if (T.slice_type == 0)
+    {
+        wave_load_window(L.win, m.ref[0], m.rv.wx0, m.rv.wy0);
+        m.rv.win = L.win;
+    }
+    STAMP(L, 1);
 
     const uint8_t *left = (m.avail & AV_L) ? L.pix_left : (const uint8_t *)0;
     const uint8_t *top = (m.avail & AV_T) ? L.pix_top : (const uint8_t *)0;
     BitW bw = L.bw;
 
     if (T.slice_type == 0) inter_choose(L, m);
+    STAMP(L, 7);
     if (m.type >= 0)
     {
         intra16_choose(L, m, left, top);
+        STAMP(L, 8);
         if (T.speed < 2 || T.slice_type != 0) intra4_choose(L, m);
+        STAMP(L, 9);
     }
     if (m.type >= 5) wave_pred_chroma(L.pred_c, left ? left + 16 : (const uint8_t *)0, top ? top + 16 : (const uint8_t *)0, m.i16_mode);
     else predict_chroma_inter(L, m);
 
+    STAMP(L, 10);
     mb_write(L, m, bw);
     L.bw = bw;
+    STAMP(L, 11);
 
     /* record for the mv_clusters validation (h264-lab.h:5776-5779 updates them with mv[0] of every non-intra MB) */
     {
@@ -245,6 +269,8 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
     L.left_type = m.type;
     L.left_qp = T.qp;
     wave_sync();
+    STAMP(L, 12);
+    L.prof[20 + (m.type < 0 ? 0 : m.type < 5 ? 1 : 2)]++;
 }
 
 DEV void row_end(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, int row)
@@ -262,6 +288,9 @@ DEV void row_end(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, i
     M.trail_skips = L.coded_any ? L.skip_run : 0;
     M.overflow = bw.overflow;
     wave_sync();
+#if defined(H264E_STAMPS) && !defined(H264E_EMU)
+    if (threadIdx.x < 32 && C.prof) atomicAdd(C.prof + threadIdx.x, L.prof[threadIdx.x]);
+#endif
 }
 
 /* ------------------------------------------------------------------ slice splice (one wavefront per chain) */

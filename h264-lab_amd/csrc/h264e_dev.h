@@ -79,6 +79,7 @@ typedef struct
     uint32_t arena_cap;
     uint32_t *cursor;
     h264e_frameout_t *fout;             /* [frame slots] */
+    unsigned long long *prof;           /* [32] phase cycle sums, written only by the -DH264E_STAMPS diagnostic build */
 } h264e_chain_dev_t;
 
 typedef struct

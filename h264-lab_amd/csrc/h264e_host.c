@@ -722,6 +722,9 @@ int H264E_clip_generate_synth(H264E_clip_t *c, int first, int nframes, int t0, u
     return h264e_hip_sync(c->pool);
 }
 
+/* diagnostic (stamps build): per-phase cycle sums since the last call */
+int H264E_clip_stamps(H264E_clip_t *c, unsigned long long *dst) { return c ? h264e_hip_stamps_read(c->pool, dst, 1) : -1; }
+
 int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_bytes, int *frame_bytes, int profile, H264E_clip_stats_t *st)
 {
     const int qp = c->par.qp, nmb = c->seq.nmb, G = c->gop_len, no_deblock = (c->par.speed == 8 || c->par.speed == 10);

@@ -33,7 +33,7 @@ extern "C" const char *h264e_hip_last_error(void) { return g_err; }
 
 #define SPIN_LIMIT (1u << 22)
 
-__global__ void __launch_bounds__(64) h264e_mb_kernel(h264e_geom_t G, const h264e_chain_dev_t *chains,
+__global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h264e_chain_dev_t *chains,
                                                       const h264e_frame_task_t *tasks, int nchains, int *errflag)
 {
     __shared__ RowLds L;
@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(64) h264e_mb_kernel(h264e_geom_t G, const h264
                 __syncthreads();
             }
         }
+        STAMP(L, 13);
         row_step(L, G, C, T, row, x);
         /* producer: drain every lane's stores, agent-scope release (L2 write-back), then the counter */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -84,6 +85,7 @@ __global__ void __launch_bounds__(64) h264e_mb_kernel(h264e_geom_t G, const h264
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(C.progress + row, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        STAMP(L, 14);
     }
     row_end(L, G, C, row);
 }
@@ -204,7 +206,7 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
         {
             h264e_chain_dev_t &C = p->chains_host[c];
             dev_free(C.rec[0][0]); dev_free(C.bottom); dev_free(C.rowbits); dev_free(C.rowmeta);
-            dev_free(C.mbrec); dev_free(C.arena); dev_free(C.cursor); dev_free(C.fout);
+            dev_free(C.mbrec); dev_free(C.arena); dev_free(C.cursor); dev_free(C.fout); dev_free(C.prof);
             if (p->clu_dev) dev_free(p->clu_dev[c]);
         }
     dev_free(p->clip); dev_free(p->chains_dev); dev_free(p->tasks_dev); dev_free(p->progress_all); dev_free(p->errflag);
@@ -281,6 +283,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         C.arena_cap = arena_cap;
         bad |= dev_malloc((void **)&C.cursor, 16);
         bad |= dev_malloc((void **)&C.fout, sizeof(h264e_frameout_t)*(size_t)slots);
+        bad |= dev_malloc((void **)&C.prof, sizeof(unsigned long long)*32);
     }
     if (bad)
     {
@@ -290,7 +293,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
 #ifdef H264E_EMU
     memcpy(p->chains_dev, p->chains_host, sizeof(h264e_chain_dev_t)*(size_t)nchains);
 #else
-    for (int c = 0; c < nchains; c++) (void)hipMemset(p->chains_host[c].cursor, 0, 16);
+    for (int c = 0; c < nchains; c++) { (void)hipMemset(p->chains_host[c].cursor, 0, 16); (void)hipMemset(p->chains_host[c].prof, 0, 256); }
     (void)hipMemset(p->errflag, 0, sizeof(int));
     if (hipMemcpy(p->chains_dev, p->chains_host, sizeof(h264e_chain_dev_t)*(size_t)nchains, hipMemcpyHostToDevice) != hipSuccess)
     {
@@ -589,6 +592,27 @@ extern "C" int h264e_hip_rewind_frame(h264e_hip_pool_t *p, int chain, int slot)
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipMemcpyAsync(p->chains_host[chain].cursor, &p->chains_host[chain].fout[slot].offset, sizeof(uint32_t), hipMemcpyDeviceToDevice, p->stream));
 #endif
+    return 0;
+}
+
+/* diagnostic: per-phase cycle sums of the -DH264E_STAMPS build, summed over chains (zeros in the product build) */
+extern "C" int h264e_hip_stamps_read(h264e_hip_pool_t *p, unsigned long long *dst /* [32] */, int reset)
+{
+    if (!p || !dst) FAIL("stamps_read: bad argument");
+    memset(dst, 0, 32*sizeof(unsigned long long));
+    for (int c = 0; c < p->nchains; c++)
+    {
+        unsigned long long t[32];
+#ifdef H264E_EMU
+        memcpy(t, p->chains_host[c].prof, sizeof(t));
+        if (reset) memset(p->chains_host[c].prof, 0, sizeof(t));
+#else
+        HIPCHK(hipSetDevice(p->device));
+        HIPCHK(hipMemcpy(t, p->chains_host[c].prof, sizeof(t), hipMemcpyDeviceToHost));
+        if (reset) HIPCHK(hipMemset(p->chains_host[c].prof, 0, sizeof(t)));
+#endif
+        for (int i = 0; i < 32; i++) dst[i] += t[i];
+    }
     return 0;
 }
 

@@ -28,6 +28,7 @@
 #endif
 DEV void wave_sync() {}
 DEV int wave_lane() { return 0; }
+DEV int uni(int v) { return v; }
 template <class F> DEV int wave_sum(F f)
 {
     int s = 0;
@@ -69,18 +70,26 @@ DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 #define DEV static __device__ __forceinline__
 #define DCONST static __device__ const
 #define WAVE_FOR(l) for (int l = (int)threadIdx.x, _w1 = 1; _w1; _w1 = 0)
-/* single-wave workgroup: the barrier only orders this wave's LDS/global traffic for the compiler and the LDS queue */
-DEV void wave_sync() { __syncthreads(); }
+/* Single-wave workgroup: LDS operations of one wavefront execute in program order, so making one lane's LDS
+ * store visible to another lane only needs the COMPILER to keep the order: a wavefront-scope fence (no
+ * instruction) plus a wave barrier (keeps the lanes converged across it). */
+DEV void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 DEV int wave_lane() { return (int)threadIdx.x; }
+/* a value every lane holds identically: move it to a scalar register so the control code runs on the scalar unit */
+DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+/* sum over the 64 lanes: DPP inside rows of 16 (quad swaps, half-row and row mirror), then 4 v_readlane */
 DEV int wave_reduce_add(int v)
 {
-    v += __shfl_xor(v, 32);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 1);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);      /* quad_perm [1,0,3,2] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);      /* quad_perm [2,3,0,1] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);     /* row_half_mirror */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);     /* row_mirror */
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 template <class F> DEV int wave_sum(F f) { return wave_reduce_add(f((int)threadIdx.x)); }
 template <class F> DEV void wave_sum4(F f, int out[4])
@@ -98,6 +107,13 @@ template <class F> DEV uint64_t wave_ballot(F f) { return __ballot(f((int)thread
 DEV uint32_t sad4_u8(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
 DEV int clz32(uint32_t v) { return __clz((int)v); }
 DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+#endif
+
+/* diagnostic build only (-DH264E_STAMPS): cycle stamps per pipeline phase, accumulated in LDS (never in the product) */
+#if defined(H264E_STAMPS) && !defined(H264E_EMU)
+#define STAMP(L, id) do { unsigned long long t_ = __builtin_readcyclecounter(); (L).prof[id] += t_ - (L).prof_last; (L).prof_last = t_; } while (0)
+#else
+#define STAMP(L, id) do { } while (0)
 #endif
 
 DEV int imin(int a, int b) { return a < b ? a : b; }

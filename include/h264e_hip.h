@@ -77,6 +77,8 @@ int  h264e_hip_rewind_frame(h264e_hip_pool_t *pool, int chain, int slot);
 /* kernel timing on the pool's stream (HIP events around every macroblock-kernel launch) */
 void h264e_hip_profile(h264e_hip_pool_t *pool, int enable);
 int  h264e_hip_profile_read(h264e_hip_pool_t *pool, double *mb_kernel_ms, double *splice_kernel_ms, int *launches);
+/* diagnostic: per-phase cycle sums of a -DH264E_STAMPS build of the kernels (all zero in the product build) */
+int  h264e_hip_stamps_read(h264e_hip_pool_t *pool, unsigned long long *dst /* [32] */, int reset);
 /* wall clock of a region on the pool's stream, by HIP events */
 int  h264e_hip_timer_start(h264e_hip_pool_t *pool);
 int  h264e_hip_timer_stop(h264e_hip_pool_t *pool, double *ms);

@@ -139,6 +139,8 @@ int  H264E_clip_generate_synth(H264E_clip_t *clip, int first, int nframes, int t
 int  H264E_clip_encode(H264E_clip_t *clip, uint8_t *out, size_t cap, size_t *out_bytes, int *frame_bytes /* [nframes] or NULL */,
                        int profile, H264E_clip_stats_t *stats);
 void H264E_clip_close(H264E_clip_t *clip);
+/* diagnostic: per-phase cycle sums [32] of a -DH264E_STAMPS kernel build since the last call (zeros in the product) */
+int  H264E_clip_stamps(H264E_clip_t *clip, unsigned long long *dst);
 
 #ifdef __cplusplus
 }
