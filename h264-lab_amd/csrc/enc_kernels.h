@@ -78,20 +78,15 @@ DEV uint32_t bw_bits(const BitW &b) { return b.pos*32u + (uint32_t)b.nacc; }
 
 /* ------------------------------------------------------------------ picture access */
 
-struct Plane { const uint8_t *p; int w, h, stride; };
+struct Plane { const gu8 *p; int w, h, stride; };
 
 /* four samples (x..x+3, y), little-endian packed, coordinates clamped to the picture: this IS the
  * reference's border extension (H:2232-2248) without storing the border */
 DEV uint32_t ref_load4(const Plane &P, int x, int y)
 {
     y = imin(imax(y, 0), P.h - 1);
-    const uint8_t *r = P.p + (size_t)y*P.stride;
-    if (x >= 0 && x + 3 < P.w)
-    {
-        uint32_t v;
-        memcpy(&v, r + x, 4);
-        return v;
-    }
+    const gu8 *r = P.p + (size_t)y*P.stride;
+    if (x >= 0 && x + 3 < P.w) return *(const gu32u *)(r + x);
     uint32_t v = 0;
     for (int k = 0; k < 4; k++) v |= (uint32_t)r[imin(imax(x + k, 0), P.w - 1)] << (8*k);
     return v;
@@ -120,12 +115,12 @@ DEV uint32_t lds32u(const uint8_t *p)
 #define WIN_M 24
 #define WIN_W 64
 #define WIN_STRIDE 68       /* 17 dwords: consecutive rows start on different LDS banks */
-struct RefView { Plane P; const uint8_t *win; int wx0, wy0; };
+struct RefView { Plane P; const uint8_t *win; int has_win, wx0, wy0; };   /* win always points at the LDS window */
 
 DEV uint32_t rv_load4(const RefView &V, int x, int y)
 {
     const int lx = x - V.wx0, ly = y - V.wy0;
-    if (V.win && (unsigned)lx <= (unsigned)(WIN_W - 4) && (unsigned)ly < (unsigned)WIN_W) return lds32u(V.win + ly*WIN_STRIDE + lx);
+    if (V.has_win && (unsigned)lx <= (unsigned)(WIN_W - 4) && (unsigned)ly < (unsigned)WIN_W) return lds32u(V.win + ly*WIN_STRIDE + lx);
     return ref_load4(V.P, x, y);
 }
 
@@ -336,21 +331,21 @@ DEV void wave_interp_chroma(const Plane &RU, const Plane &RV, int cx, int cy, mv
 
 /* ------------------------------------------------------------------ intra prediction */
 
-/* H:1625-1651: mean of the available edges (NULL = unavailable) of n = 1 << lg samples each, 128 when none */
-DEV int dc_pred(const uint8_t *left, const uint8_t *top, int lg)
+/* H:1625-1651: mean of the available edges of n = 1 << lg samples each, 128 when none */
+DEV int dc_pred(const uint8_t *left, int have_left, const uint8_t *top, int have_top, int lg)
 {
     const int n = 1 << lg;
     int s = 0, sh = lg - 1;
-    if (left) { for (int i = 0; i < n; i++) s += left[i]; sh++; }
-    if (top)  { for (int i = 0; i < n; i++) s += top[i];  sh++; }
+    if (have_left) { for (int i = 0; i < n; i++) s += left[i]; sh++; }
+    if (have_top)  { for (int i = 0; i < n; i++) s += top[i];  sh++; }
     if (sh < lg) return 128;
     return (s + (1 << (sh - 1))) >> sh;
 }
 
-/* H:1677-1714: 16x16 luma prediction, mode 0 V / 1 H / 2 DC, into LDS dst */
-DEV void wave_pred16(uint8_t *dst, const uint8_t *left, const uint8_t *top, int mode)
+/* H:1677-1714: 16x16 luma prediction, mode 0 V / 1 H / 2 DC, into LDS dst; left/top are LDS lines, avail says which exist */
+DEV void wave_pred16(uint8_t *dst, const uint8_t *left, const uint8_t *top, int avail, int mode)
 {
-    const int dc = mode == 2 ? dc_pred(left, top, 4) : 0;
+    const int dc = mode == 2 ? dc_pred(left, avail & AV_L, top, avail & AV_T, 4) : 0;
     WAVE_FOR(l)
     {
         int r = l >> 2, c = l & 3;
@@ -361,24 +356,25 @@ DEV void wave_pred16(uint8_t *dst, const uint8_t *left, const uint8_t *top, int 
 }
 
 /* H:1716-1781: 8x8 U | V prediction (stride 16); left/top = 8 U then 8 V; mode in LUMA numbering */
-DEV void wave_pred_chroma(uint8_t *dst, const uint8_t *left, const uint8_t *top, int mode)
+DEV void wave_pred_chroma(uint8_t *dst, const uint8_t *left, const uint8_t *top, int avail, int mode)
 {
+    const int hl = avail & AV_L, ht = avail & AV_T;
     WAVE_FOR(l)
     {
         if (l < 32)
         {
             int pl = l >> 4, r = (l >> 1) & 7, c = l & 1;       /* plane, row, 4-sample group = one DC quadrant */
-            const uint8_t *lf = left ? left + 8*pl : 0, *tp = top ? top + 8*pl : 0;
+            const uint8_t *lf = left + 8*pl, *tp = top + 8*pl;
             uint32_t v;
             if (mode == 0) v = lds32(tp + 4*c);
             else if (mode == 1) v = (uint32_t)lf[r]*0x01010101u;
             else
             {
                 int q = (r >> 2)*2 + c, dc;
-                if (q == 0) dc = dc_pred(lf, tp, 2);
-                else if (q == 1) dc = tp ? dc_pred(0, tp + 4, 2) : dc_pred(lf, 0, 2);
-                else if (q == 2) dc = lf ? dc_pred(lf + 4, 0, 2) : dc_pred(0, tp, 2);
-                else dc = dc_pred(lf ? lf + 4 : 0, tp ? tp + 4 : 0, 2);
+                if (q == 0) dc = dc_pred(lf, hl, tp, ht, 2);
+                else if (q == 1) dc = ht ? dc_pred(lf, 0, tp + 4, 1, 2) : dc_pred(lf, hl, tp, 0, 2);
+                else if (q == 2) dc = hl ? dc_pred(lf + 4, 1, tp, 0, 2) : dc_pred(lf, 0, tp, ht, 2);
+                else dc = dc_pred(lf + 4, hl, tp + 4, ht, 2);
                 v = (uint32_t)dc*0x01010101u;
             }
             lds32_store(dst + 8*pl + 16*r + 4*c, v);

@@ -56,6 +56,7 @@ struct RowLds
     alignas(16) uint8_t p20[256];
     alignas(16) uint8_t p22[256];
     alignas(16) uint8_t tt[256];
+    alignas(16) uint8_t skip_tmp[4][256];           /* quarter-pel candidates of the sub-pel search */
     alignas(16) uint8_t i4rec[17*24];               /* intra 4x4 working picture: row 0 / column 0 = neighbours */
     alignas(16) uint8_t ytile[20*YT_STRIDE];
     alignas(16) uint8_t ctile[2][10*CT_STRIDE];
@@ -70,7 +71,7 @@ struct MbCtx
     const h264e_frame_task_t *T;
     Plane ref[3];
     RefView rv;                                     /* reference luma through the LDS window */
-    uint8_t *dec[3];
+    gu8 *dec[3];
     int x, y, num, avail, type, cost, i16_mode, cropped, used_cand;
     mv32 mv_skip_pred;
     unsigned nz_mask;
@@ -184,16 +185,42 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
     int dir, cloop, dir_prev, cost;
     mv32 v;
     mv = (mv32)uni(mv); mv_pred = (mv32)uni(mv_pred); min_sad = uni(min_sad);
+    const int g = w >> 2, n = g*h;
     for (;;)
     {
         dir = 0; cloop = 4; dir_prev = -1;
         cur = prv = ~0ull;
+        /* SADs of the centre's four neighbours are taken in one batch (one lane-parallel pass, two packed reductions) the
+         * first time the reference's sequential scan asks for one of them; the scan itself is unchanged */
+        int have = 0, bs0 = 0, bs1 = 0, bs2 = 0, bs3 = 0;
         do
         {
             v = mvadd(mv, mvmk(DX(dir), DY(dir)));
             if (in_rect(v, range) && CGET(cur, dir) == 0xffffu)
             {
-                cost = wave_sad_ref(R, px + (mvx(v) >> 2), py + (mvy(v) >> 2), b, w, h) + mv_cost(m, v, mv_pred);
+                if (!(have & (1 << dir)))
+                {
+                    int want = 0, s4[4];
+#pragma unroll
+                    for (int d = 0; d < 4; d++)
+                    {
+                        const mv32 vd2 = mvadd(mv, mvmk(DX(d), DY(d)));
+                        if (in_rect(vd2, range) && CGET(cur, d) == 0xffffu) want |= 1 << d;
+                    }
+                    const int cx = px + (mvx(mv) >> 2), cy = py + (mvy(mv) >> 2);
+                    wave_sum4([&](int l, int *sv) {
+                        if (l >= n) return;
+                        const int r = l/g, c4 = l - r*g;
+                        const uint32_t in4 = lds32(b + 16*r + 4*c4);
+                        if (want & 1) sv[0] = (int)sad4_u8(rv_load4(R, cx + 4*c4 + 1, cy + r), in4, 0);
+                        if (want & 2) sv[1] = (int)sad4_u8(rv_load4(R, cx + 4*c4 - 1, cy + r), in4, 0);
+                        if (want & 4) sv[2] = (int)sad4_u8(rv_load4(R, cx + 4*c4, cy + r + 1), in4, 0);
+                        if (want & 8) sv[3] = (int)sad4_u8(rv_load4(R, cx + 4*c4, cy + r - 1), in4, 0);
+                    }, s4);
+                    bs0 = s4[0]; bs1 = s4[1]; bs2 = s4[2]; bs3 = s4[3];
+                    have = want;
+                }
+                cost = (dir == 0 ? bs0 : dir == 1 ? bs1 : dir == 2 ? bs2 : bs3) + mv_cost(m, v, mv_pred);
                 CSET(cur, dir, (uint32_t)cost);
                 if (cost < min_sad)
                 {
@@ -207,6 +234,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
                     cloop = 4 + 1;
                     mv = v;
                     min_sad = cost;
+                    have = 0;
                 }
             }
             dir = (dir + 1) & 3;
@@ -233,37 +261,53 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
 #undef DY
 
     STAMP(L, 5);
-    wave_interp_luma(R, px, py, mv, w, h, L.blk);
-    if (m.T->speed < 9 && in_rect(mv, mv_qlimit(m)))
+    if (!(m.T->speed < 9 && in_rect(mv, mv_qlimit(m))))
     {
-        mv32 vbest = mv, pq = mvmk(0, -1), sq = mvmk(-1, 0);
+        wave_interp_luma(R, px, py, mv, w, h, L.blk);
+        STAMP(L, 6);
+        return min_sad;
+    }
+    {
+        /* H:5083-5174: seven sub-pel probes around the full-pel winner -- half-pels towards the cheaper vertical and the
+         * cheaper horizontal neighbour (02, 20), their diagonal (22), and the quarter-pels between them (01, 10, 11, 12).
+         * The reference always evaluates all seven, in this order, keeping the first strict minimum; here every lane builds
+         * its 4 samples of all seven (plus the full-pel block) in one pass and the seven SADs are reduced together. */
+        mv32 pq = mvmk(0, -1), sq = mvmk(-1, 0);
         uint32_t ms1 = c1, ms2 = c3;
-        wave_copy_wh(L.p00, L.blk, w, h);
         if (c3 >= c2) { pq = mvmk(0, 1); ms2 = c2; }
         if (c1 >= c0) { sq = mvmk(1, 0); ms1 = c0; }
         if (ms2 > ms1) { mv32 s = sq; sq = pq; pq = s; }
-        const mv32 vd = mvadd(pq, sq);
-        for (int i = 0; i < 7; i++)
-        {
-            const uint8_t *cand;
-            switch (i)
-            {
-            case 0: v = mvadd(mv, mvadd(pq, pq)); wave_interp_luma(R, px, py, v, w, h, L.p02); cand = L.p02; break;
-            case 1: v = mvadd(mv, pq); wave_avg(L.p00, L.p02, L.tt, w, h); cand = L.tt; break;
-            case 2: v = mvadd(mv, mvadd(sq, sq)); wave_interp_luma(R, px, py, v, w, h, L.p20); cand = L.p20; break;
-            case 3: v = mvadd(mv, sq); wave_avg(L.p00, L.p20, L.tt, w, h); cand = L.tt; break;
-            case 4: v = mvadd(mv, vd); wave_avg(L.p02, L.p20, L.tt, w, h); cand = L.tt; break;
-            case 5: v = mvadd(mv, mvadd(vd, vd)); wave_interp_luma(R, px, py, v, w, h, L.p22); cand = L.p22; break;
-            default: v = mvadd(mv, mvadd(pq, vd)); wave_avg(L.p22, L.p02, L.tt, w, h); cand = L.tt; break;
-            }
-            cost = wave_sad_lds(cand, b, w, h) + mv_cost(m, v, mv_pred);
-            if (cost < min_sad)
-            {
-                min_sad = cost;
-                vbest = v;
-                wave_copy_wh(L.blk, cand, w, h);
-            }
-        }
+        const mv32 vdg = mvadd(pq, sq);
+        const mv32 v02 = mvadd(mv, mvadd(pq, pq)), v01 = mvadd(mv, pq), v20 = mvadd(mv, mvadd(sq, sq)), v10 = mvadd(mv, sq);
+        const mv32 v11 = mvadd(mv, vdg), v22 = mvadd(mv, mvadd(vdg, vdg)), v12 = mvadd(mv, mvadd(pq, vdg));
+        int s8[8];
+        wave_sum8([&](int l, int *sv) {
+            if (l >= n) return;
+            const int r = l/g, c4 = l - r*g, o = 16*r + 4*c4;
+            const uint32_t in4 = lds32(b + o);
+#define IP(vv) interp_luma4(R, px + (mvx(vv) >> 2) + 4*c4, py + (mvy(vv) >> 2) + r, mvx(vv) & 3, mvy(vv) & 3)
+#define AVG4(x, y) (((x) | (y)) - ((((x) ^ (y)) >> 1) & 0x7f7f7f7fu))                    /* per-byte (x + y + 1) >> 1 */
+            const uint32_t q00 = IP(mv), q02 = IP(v02), q20 = IP(v20), q22 = IP(v22);
+#undef IP
+            const uint32_t q01 = AVG4(q00, q02), q10 = AVG4(q00, q20), q11 = AVG4(q02, q20), q12 = AVG4(q22, q02);
+#undef AVG4
+            lds32_store(L.p00 + o, q00);
+            lds32_store(L.p02 + o, q02); lds32_store(L.p20 + o, q20); lds32_store(L.p22 + o, q22);
+            lds32_store(L.skip_tmp[0] + o, q01); lds32_store(L.skip_tmp[1] + o, q10);
+            lds32_store(L.skip_tmp[2] + o, q11); lds32_store(L.skip_tmp[3] + o, q12);
+            sv[0] = (int)sad4_u8(q02, in4, 0); sv[1] = (int)sad4_u8(q01, in4, 0); sv[2] = (int)sad4_u8(q20, in4, 0);
+            sv[3] = (int)sad4_u8(q10, in4, 0); sv[4] = (int)sad4_u8(q11, in4, 0); sv[5] = (int)sad4_u8(q22, in4, 0);
+            sv[6] = (int)sad4_u8(q12, in4, 0);
+        }, s8);
+        wave_sync();
+        int best = -1;
+        mv32 vbest = mv;
+#define TRY(i, vv) { const int cst = s8[i] + mv_cost(m, vv, mv_pred); if (cst < min_sad) { min_sad = cst; vbest = vv; best = i; } }
+        TRY(0, v02) TRY(1, v01) TRY(2, v20) TRY(3, v10) TRY(4, v11) TRY(5, v22) TRY(6, v12)
+#undef TRY
+        const uint8_t *src = best < 0 ? L.p00 : best == 0 ? L.p02 : best == 1 ? L.skip_tmp[0] : best == 2 ? L.p20 : best == 3 ? L.skip_tmp[1] :
+                             best == 4 ? L.skip_tmp[2] : best == 5 ? L.p22 : L.skip_tmp[3];
+        wave_copy_wh(L.blk, src, w, h);
         mv = vbest;
     }
     STAMP(L, 6);
@@ -481,7 +525,7 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
 /* ------------------------------------------------------------------ intra decisions */
 
 /* H:4838-4858 intra_estimate_16x16 + H:4876-4896 intra_choose_16x16 */
-DEV void intra16_choose(RowLds &L, MbCtx &m, const uint8_t *left, const uint8_t *top)
+DEV void intra16_choose(RowLds &L, MbCtx &m)
 {
     const uint8_t *p = L.inp;
     const int v = m.avail & 3;             /* H:4840 mode_i16x16_valid: bit 0 = vertical allowed (top), bit 1 = horizontal (left) */
@@ -492,7 +536,7 @@ DEV void intra16_choose(RowLds &L, MbCtx &m, const uint8_t *left, const uint8_t 
     else if (dy > 30 + 3*dx && dx < (100 + 50 - m.qp) && (v & 2)) mode = 1;
     else mode = 2;
     m.i16_mode = mode;
-    wave_pred16(L.test, left, top, mode);
+    wave_pred16(L.test, L.pix_left, L.pix_top, m.avail, mode);
     int sad = wave_sad_lds_q(L.inp, L.test, sad4) + MUL_LAMBDA(ue_len((uint32_t)mode + 1), m.lambda_q4) + m.lambda_i16;
     if (sad < m.cost)
     {
@@ -512,6 +556,7 @@ DEV void intra4_choose(RowLds &L, MbCtx &m)
     const int avail = m.avail;
     int cost = m.lambda_i4;
     unsigned nz_mask = 0;
+    if (cost >= m.cost) return;
     WAVE_FOR(l)
     {
         if (l < 16) { r0[-24 + l] = L.pix_top[l]; r0[24*l - 1] = L.pix_left[l]; }
@@ -548,6 +593,9 @@ DEV void intra4_choose(RowLds &L, MbCtx &m)
         }
         nz_mask = (nz_mask << 1) | coded;
         cost += sad;
+        /* the cost only grows: once it reaches the best cost so far intra 4x4 cannot win (H:4827) and nothing else of this
+         * function is observable for another macroblock type -- mb_write resets the mode contexts and recomputes luma */
+        if (cost >= m.cost) return;
         WAVE_FOR(l) { if (l < 4) lds32_store(blk + 24*l, lds32(pr + 16*l)); }
         wave_sync();
     }

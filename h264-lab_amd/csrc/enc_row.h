@@ -79,7 +79,7 @@ DEV void load_input(RowLds &L, const h264e_geom_t &G, const h264e_frame_task_t &
     {
         {
             int r = l >> 2, c = l & 3, yy = imin(mby*16 + r, G.height - 1);
-            const uint8_t *p = T.in[0] + (size_t)yy*T.in_stride[0];
+            const gu8 *p = (const gu8 *)T.in[0] + (size_t)yy*T.in_stride[0];
             uint32_t v = 0;
             for (int k = 0; k < 4; k++) v |= (uint32_t)p[imin(mbx*16 + 4*c + k, G.width - 1)] << (8*k);
             lds32_store(L.inp + 16*r + 4*c, v);
@@ -87,7 +87,7 @@ DEV void load_input(RowLds &L, const h264e_geom_t &G, const h264e_frame_task_t &
         if (l < 32)
         {
             int pl = l >> 4, r = (l >> 1) & 7, c = l & 1, yy = imin(mby*8 + r, G.height/2 - 1);
-            const uint8_t *p = T.in[1 + pl] + (size_t)yy*T.in_stride[1 + pl];
+            const gu8 *p = (const gu8 *)T.in[1 + pl] + (size_t)yy*T.in_stride[1 + pl];
             uint32_t v = 0;
             for (int k = 0; k < 4; k++) v |= (uint32_t)p[imin(mbx*8 + 4*c + k, G.width/2 - 1)] << (8*k);
             lds32_store(L.inp_c + 16*r + 8*pl + 4*c, v);
@@ -102,9 +102,9 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
     m.G = &G; m.T = &T;
     for (int c = 0; c < 3; c++)
     {
-        m.ref[c].p = C.rec[T.ref_sel][c];
+        m.ref[c].p = (const gu8 *)C.rec[T.ref_sel][c];
         m.ref[c].w = G.W >> (c ? 1 : 0); m.ref[c].h = G.H >> (c ? 1 : 0); m.ref[c].stride = m.ref[c].w;
-        m.dec[c] = C.rec[T.ref_sel ^ 1][c];
+        m.dec[c] = (gu8 *)C.rec[T.ref_sel ^ 1][c];
     }
     m.x = x; m.y = row; m.num = row*G.nmbx + x;
     m.avail = (row > 0 ? AV_T : 0) | (row > 0 && x != G.nmbx - 1 ? AV_TR : 0) | (x > 0 ? AV_L : 0) | (row > 0 && x > 0 ? AV_TL : 0);
@@ -118,28 +118,26 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
     STAMP(L, 0);
     load_top(L, G, rowrec - G.nmbx, x, row > 0);
     load_input(L, G, T, x, row);
-    m.rv.P = m.ref[0]; m.rv.win = (const uint8_t *)0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
+    m.rv.P = m.ref[0]; m.rv.win = L.win; m.rv.has_win = 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
     if (T.slice_type == 0)
     {
         wave_load_window(L.win, m.ref[0], m.rv.wx0, m.rv.wy0);
-        m.rv.win = L.win;
+        m.rv.has_win = 1;
     }
     STAMP(L, 1);
 
-    const uint8_t *left = (m.avail & AV_L) ? L.pix_left : (const uint8_t *)0;
-    const uint8_t *top = (m.avail & AV_T) ? L.pix_top : (const uint8_t *)0;
     BitW bw = L.bw;
 
     if (T.slice_type == 0) inter_choose(L, m);
     STAMP(L, 7);
     if (m.type >= 0)
     {
-        intra16_choose(L, m, left, top);
+        intra16_choose(L, m);
         STAMP(L, 8);
         if (T.speed < 2 || T.slice_type != 0) intra4_choose(L, m);
         STAMP(L, 9);
     }
-    if (m.type >= 5) wave_pred_chroma(L.pred_c, left ? left + 16 : (const uint8_t *)0, top ? top + 16 : (const uint8_t *)0, m.i16_mode);
+    if (m.type >= 5) wave_pred_chroma(L.pred_c, L.pix_left + 16, L.pix_top + 16, m.avail, m.i16_mode);
     else predict_chroma_inter(L, m);
 
     STAMP(L, 10);
@@ -181,8 +179,8 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
 
     /* deblock on the LDS tiles: left strips from LDS (previous macroblock), top strips from HBM (row above) */
     const int W = G.W, Wc = G.W >> 1;
-    uint8_t *dy = m.dec[0] + (size_t)(row*16)*W + x*16;
-    uint8_t *du = m.dec[1] + (size_t)(row*8)*Wc + x*8, *dv = m.dec[2] + (size_t)(row*8)*Wc + x*8;
+    gu8 *dy = m.dec[0] + (size_t)(row*16)*W + x*16;
+    gu8 *du = m.dec[1] + (size_t)(row*8)*Wc + x*8, *dv = m.dec[2] + (size_t)(row*8)*Wc + x*8;
     if (!T.no_deblock)
     {
         df_strength(L, m, L.top_type);
@@ -198,12 +196,12 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
             {
                 int r = (l - 32) >> 2, c = l & 3;
                 uint32_t v = 0;
-                if (row > 0) memcpy(&v, dy - (size_t)(4 - r)*W + 4*c, 4);
+                if (row > 0) v = gload32(dy - (size_t)(4 - r)*W + 4*c);
                 lds32_store(L.ytile + r*YT_STRIDE + 4 + 4*c, v);
             } else if (l < 56)
             {
                 int pl = (l >> 2) & 1, r = (l >> 1) & 1, c = l & 1;
-                const uint8_t *s = (pl ? dv : du) - (size_t)(2 - r)*Wc + 4*c;
+                const gu8 *s = (pl ? dv : du) - (size_t)(2 - r)*Wc + 4*c;
                 uint8_t *t = L.ctile[pl] + r*CT_STRIDE + 2 + 4*c;
                 for (int k = 0; k < 4; k++) t[k] = row > 0 ? s[k] : 0;
             }
@@ -216,12 +214,12 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
     {
         int r = l >> 2, c = l & 3;
         uint32_t v = lds32(ty + YT_STRIDE*r + 4*c);
-        memcpy(dy + (size_t)r*W + 4*c, &v, 4);
+        gstore32(dy + (size_t)r*W + 4*c, v);
         if (l < 32)
         {
             int pl = l >> 4, rr = (l >> 1) & 7, g = l & 1;
             uint32_t u = lds32((pl ? tc1 : tc0) + CT_STRIDE*rr + 4*g);
-            memcpy((pl ? dv : du) + (size_t)rr*Wc + 4*g, &u, 4);
+            gstore32((pl ? dv : du) + (size_t)rr*Wc + 4*g, u);
         }
     }
     if (!T.no_deblock)
@@ -230,11 +228,11 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
         {
             if (l < 16)
             {
-                if (x > 0) { uint32_t v = lds32(L.ytile + (4 + l)*YT_STRIDE); memcpy(dy + (size_t)l*W - 4, &v, 4); }
+                if (x > 0) { uint32_t v = lds32(L.ytile + (4 + l)*YT_STRIDE); gstore32(dy + (size_t)l*W - 4, v); }
             } else if (l < 28)
             {
                 int r = 1 + (l - 16)/4, c = l & 3;                          /* rows -3..-1 of the tile = rows 1..3 */
-                if (row > 0) { uint32_t v = lds32(L.ytile + r*YT_STRIDE + 4 + 4*c); memcpy(dy - (size_t)(4 - r)*W + 4*c, &v, 4); }
+                if (row > 0) { uint32_t v = lds32(L.ytile + r*YT_STRIDE + 4 + 4*c); gstore32(dy - (size_t)(4 - r)*W + 4*c, v); }
             } else if (l < 44)
             {
                 int pl = (l - 28) >> 3, i = (l - 28) & 7;
@@ -242,7 +240,7 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
             } else if (l < 48)
             {
                 int pl = (l - 44) >> 1, c = l & 1;
-                if (row > 0) { uint32_t v; memcpy(&v, L.ctile[pl] + CT_STRIDE + 2 + 4*c, 4); memcpy((pl ? dv : du) - Wc + 4*c, &v, 4); }
+                if (row > 0) { uint32_t v; memcpy(&v, L.ctile[pl] + CT_STRIDE + 2 + 4*c, 4); gstore32((pl ? dv : du) - Wc + 4*c, v); }
             }
         }
     }
@@ -359,7 +357,7 @@ DEV void clusters_step(mv32 c[2], mv32 mv)                                  /* h
     if (n >= n0) c[1] = mvmk((63*mvx(c[1]) + mvx(mv) + 32) >> 6, (63*mvy(c[1]) + mvy(mv) + 32) >> 6);
 }
 
-DEV void finalize_frame(const h264e_geom_t &G, const h264e_chain_dev_t &C, const h264e_frame_task_t &T)
+DEV void finalize_frame(const h264e_geom_t &G, const h264e_chain_dev_t &C, const h264e_frame_task_t &T, int *stepflags)
 {
     SpliceState s;
     const uint32_t start = (*C.cursor + 3u) & ~3u;
@@ -412,6 +410,8 @@ DEV void finalize_frame(const h264e_geom_t &G, const h264e_chain_dev_t &C, const
     F.clusters_moved = moved;
     F.overflow = overflow | s.overflow;
     *C.cursor = start + ((nbytes + 3u) & ~3u);
+    stepflags[0] = moved;
+    stepflags[1] = overflow | s.overflow;
     wave_sync();
 }
 

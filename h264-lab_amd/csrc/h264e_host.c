@@ -378,51 +378,70 @@ static void rc_frame_end(rc_t *rc, int nmb, int vbv_size_bytes, int desired_fram
 /* ------------------------------------------------------------------ one frame on one chain, validated */
 
 /*
- * Encode one frame on `chain` and make the mv_clusters speculation exact: submit with the frame-constant
- * value; when the kernel reports that some update would move the state, walk the exact trajectory and, if a
- * consumed rounded candidate differs, re-encode with per-macroblock values until the walk is consistent
- * (every pass fixes at least the first offending macroblock, so this terminates).
+ * One step (one frame of every active chain) with the mv_clusters speculation made exact.
+ * tasks[k].mv_clusters holds the state in front of chain k's frame (run[k]); the kernel uses it for every
+ * macroblock.  Chains whose frame moves the state are walked exactly; where a consumed rounded candidate
+ * differs, those chains (all of them together, one launch) are encoded again with the walked per-macroblock
+ * values, until the walk is consistent -- every pass fixes at least the first offending macroblock of each
+ * chain, so this terminates.  run[k] is advanced to the state behind the frame; arr_out[k] (optional) receives
+ * the per-macroblock array the final pass used (caller frees) or NULL.
  */
-static int encode_frame_exact(h264e_hip_pool_t *pool, int nchains, int chain, h264e_hip_task_t *task, int nmb,
-                              int32_t clusters[2], h264e_hip_result_t *res, int *passes)
+static int step_exact(h264e_hip_pool_t *pool, int nchains, h264e_hip_task_t *tasks, int nmb, int32_t (*run)[2],
+                      int32_t **arr_out, int *extra_passes)
 {
-    h264e_hip_task_t *tasks = (h264e_hip_task_t *)calloc((size_t)nchains, sizeof(*tasks));
+    int *flags = (int *)calloc(2*(size_t)nchains, sizeof(int));
+    int32_t **arr = (int32_t **)calloc((size_t)nchains, sizeof(int32_t *));
+    char *todo = (char *)calloc((size_t)nchains, 1);
     h264e_hip_mbrec_t *rec = NULL;
-    int32_t *traj = NULL, *used = NULL;
-    int rc = -1, pass;
-    if (!tasks) return -1;
-    task->mv_clusters[0] = clusters[0]; task->mv_clusters[1] = clusters[1];
-    task->mv_clusters_per_mb = NULL;
-    for (pass = 0; pass < nmb + 2; pass++)
+    int32_t *traj = NULL;
+    int rc = -1, k, pass, pending = 0;
+    if (!flags || !arr || !todo) goto done;
+    for (k = 0; k < nchains; k++)
     {
-        int32_t c[2] = { clusters[0], clusters[1] };
-        int bad;
-        tasks[chain] = *task;
-        if (h264e_hip_submit(pool, tasks) || h264e_hip_sync(pool) || h264e_hip_result(pool, chain, task->frame_slot, res)) goto done;
-        if (res->overflow) { snprintf(g_host_err, sizeof(g_host_err), "bit buffer overflow"); goto done; }
-        if (!task->mv_clusters_per_mb && !res->clusters_moved) { rc = 0; break; }      /* fixed point: nothing to do */
-        if (!rec)
-        {
-            rec = (h264e_hip_mbrec_t *)malloc(sizeof(*rec)*(size_t)nmb);
-            traj = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb);
-            used = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb);
-            if (!rec || !traj || !used) goto done;
-        }
-        if (h264e_hip_read_mbrec(pool, chain, task->frame_slot, rec)) goto done;
-        bad = clusters_walk(c, rec, nmb, task->mv_clusters_per_mb ? used : task->mv_clusters, task->mv_clusters_per_mb != NULL, traj);
-        if (bad < 0)
-        {
-            clusters[0] = c[0]; clusters[1] = c[1];
-            rc = 0;
-            break;
-        }
-        memcpy(used, traj, sizeof(int32_t)*2*(size_t)nmb);
-        task->mv_clusters_per_mb = used;
-        if (h264e_hip_rewind_frame(pool, chain, task->frame_slot)) goto done;
+        tasks[k].mv_clusters_per_mb = NULL;
+        if (tasks[k].active) { tasks[k].mv_clusters[0] = run[k][0]; tasks[k].mv_clusters[1] = run[k][1]; todo[k] = 1; pending++; }
     }
-    if (passes) *passes = pass + 1;
+    for (pass = 0; pending; pass++)
+    {
+        if (pass > nmb + 2) { snprintf(g_host_err, sizeof(g_host_err), "mv_clusters re-encode does not converge"); goto done; }
+        if (h264e_hip_submit(pool, tasks) || h264e_hip_sync(pool) || h264e_hip_step_flags(pool, flags)) goto done;
+        for (k = 0; k < nchains; k++)
+        {
+            int32_t cc[2];
+            int bad;
+            if (!todo[k]) continue;
+            if (flags[2*k + 1]) { snprintf(g_host_err, sizeof(g_host_err), "bit buffer overflow"); goto done; }
+            if (!arr[k] && !flags[2*k]) { todo[k] = 0; tasks[k].active = 0; pending--; continue; }   /* fixed point: state unchanged */
+            if (!rec)
+            {
+                rec = (h264e_hip_mbrec_t *)malloc(sizeof(*rec)*(size_t)nmb);
+                traj = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb);
+                if (!rec || !traj) goto done;
+            }
+            if (h264e_hip_read_mbrec(pool, k, tasks[k].frame_slot, rec)) goto done;
+            cc[0] = run[k][0]; cc[1] = run[k][1];
+            bad = clusters_walk(cc, rec, nmb, arr[k] ? arr[k] : run[k], arr[k] != NULL, traj) >= 0;
+            if (!bad)
+            {
+                run[k][0] = cc[0]; run[k][1] = cc[1];
+                todo[k] = 0; tasks[k].active = 0; pending--;
+                continue;
+            }
+            if (!arr[k]) arr[k] = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb);
+            if (!arr[k]) goto done;
+            memcpy(arr[k], traj, sizeof(int32_t)*2*(size_t)nmb);
+            tasks[k].mv_clusters_per_mb = arr[k];
+            if (h264e_hip_rewind_frame(pool, k, tasks[k].frame_slot)) goto done;
+        }
+    }
+    if (extra_passes) *extra_passes = pass > 0 ? pass - 1 : 0;
+    rc = 0;
 done:
-    free(tasks); free(rec); free(traj); free(used);
+    for (k = 0; k < nchains && arr; k++)
+    {
+        if (!rc && arr_out) arr_out[k] = arr[k]; else free(arr[k]);
+    }
+    free(flags); free(arr); free(todo); free(rec); free(traj);
     return rc;
 }
 
@@ -627,7 +646,11 @@ int H264E_encode(H264E_persist_t *p, H264E_scratch_t *scratch, const H264E_run_p
 
     yuv[0] = in->yuv[0]; yuv[1] = in->yuv[1]; yuv[2] = in->yuv[2];
     if (h264e_hip_reset_results(m->pool, 0) || h264e_hip_upload_planes(m->pool, 0, yuv, in->stride)) return H264E_STATUS_BAD_ARGUMENT;
-    if (encode_frame_exact(m->pool, 1, 0, &task, e->seq.nmb, e->clusters, &res, NULL)) return H264E_STATUS_BAD_ARGUMENT;
+    {
+        int32_t run[1][2] = { { e->clusters[0], e->clusters[1] } };
+        if (step_exact(m->pool, 1, &task, e->seq.nmb, run, NULL, NULL) || h264e_hip_result(m->pool, 0, 0, &res)) return H264E_STATUS_BAD_ARGUMENT;
+        e->clusters[0] = run[0][0]; e->clusters[1] = run[0][1];
+    }
     if (res.nbytes > m->rbsp_cap) return H264E_STATUS_BAD_ARGUMENT;
     n = h264e_hip_read_rbsp(m->pool, 0, 0, m->rbsp, (uint32_t)m->rbsp_cap);
     if (n < 0) return H264E_STATUS_BAD_ARGUMENT;
@@ -725,135 +748,207 @@ int H264E_clip_generate_synth(H264E_clip_t *c, int first, int nframes, int t0, u
 /* diagnostic (stamps build): per-phase cycle sums since the last call */
 int H264E_clip_stamps(H264E_clip_t *c, unsigned long long *dst) { return c ? h264e_hip_stamps_read(c->pool, dst, 1) : -1; }
 
+/*
+ * One GOP of the clip encoder.  A GOP is encoded against an ASSUMED mv_clusters input state (the state in front
+ * of its key frame); inside the GOP the state is tracked exactly, frame by frame.  After all earlier GOPs are
+ * known, the GOP is valid if the candidates it consumed equal the ones the true input state gives.
+ */
+typedef struct
+{
+    int encoded, valid, nf;
+    int32_t in_state[2], out_state[2], true_out[2];
+    int32_t (*used_const)[2];           /* [nf] frame-constant value handed to the kernel ... */
+    int32_t **used_arr;                 /* [nf] ... or the per-macroblock array (exact re-encode of a frame) */
+    h264e_hip_mbrec_t *rec;             /* [nf][nmb] */
+    uint8_t *rbsp; uint32_t rbsp_bytes;
+    uint32_t *off, *len;                /* [nf] */
+} gop_t;
+
+static void gop_free(gop_t *g)
+{
+    int f;
+    if (g->used_arr) for (f = 0; f < g->nf; f++) free(g->used_arr[f]);
+    free(g->used_const); free(g->used_arr); free(g->rec); free(g->rbsp); free(g->off); free(g->len);
+    memset(g, 0, sizeof(*g));
+}
+
+/* walk the GOP's records from `in`: returns 0 when every consumed rounded candidate equals what the kernel used */
+static int gop_check(const gop_t *g, int nmb, const int32_t in[2], int32_t out[2])
+{
+    int32_t c[2] = { in[0], in[1] };
+    int f, bad = 0;
+    for (f = 0; f < g->nf; f++)
+    {
+        const int per_mb = g->used_arr[f] != NULL;
+        if (clusters_walk(c, g->rec + (size_t)f*nmb, nmb, per_mb ? g->used_arr[f] : g->used_const[f], per_mb, NULL) >= 0) bad = 1;
+    }
+    out[0] = c[0]; out[1] = c[1];
+    return bad;
+}
+
 int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_bytes, int *frame_bytes, int profile, H264E_clip_stats_t *st)
 {
     const int qp = c->par.qp, nmb = c->seq.nmb, G = c->gop_len, no_deblock = (c->par.speed == 8 || c->par.speed == 10);
     const int pic_init_qp = imax(imin(30, qp), qp);     /* qp_min = qp_max = qp (h264-lab.h:6768-6770) */
+    const int idr_state = c->par.first_idr_pic_id_state & 1;
     h264e_hip_task_t *tasks = (h264e_hip_task_t *)calloc((size_t)c->nchains, sizeof(*tasks));
     h264e_hip_result_t *res = (h264e_hip_result_t *)calloc((size_t)G, sizeof(*res));
-    uint32_t *offs = (uint32_t *)calloc((size_t)G, sizeof(uint32_t));
+    gop_t *gops = (gop_t *)calloc((size_t)c->ngops, sizeof(gop_t));
+    int *sel = (int *)calloc((size_t)c->nchains, sizeof(int)), *flags = (int *)calloc(2*(size_t)c->nchains, sizeof(int));
+    int32_t **arrs = (int32_t **)calloc((size_t)c->nchains, sizeof(int32_t *));
+    int32_t (*run)[2] = (int32_t (*)[2])calloc((size_t)c->nchains, sizeof(int32_t[2]));
     const uint32_t arena_cap = (uint32_t)((size_t)G*((size_t)nmb*640 + 1024));
     uint8_t *arena = (uint8_t *)malloc(arena_cap);
-    h264e_hip_mbrec_t *rec = NULL;
-    int32_t clusters[2] = { c->par.mv_clusters_in[0], c->par.mv_clusters_in[1] };
-    int idr_state = c->par.first_idr_pic_id_state & 1;
     uint16_t qdat_i[2][42], qdat_p[2][42];
     size_t pos = 0;
-    int round, rc = -1, f, k;
+    int rc = -1, f, k, g, first_open = 0;
     H264E_clip_stats_t stats;
     double t0;
     memset(&stats, 0, sizeof(stats));
     g_host_err[0] = 0;
-    if (!tasks || !res || !offs || !arena) goto done;
+    if (!tasks || !res || !gops || !sel || !flags || !run || !arena || !arrs) goto done;
     build_qdat(qdat_i, qp, 0);
     build_qdat(qdat_p, qp, 1);
     h264e_hip_profile(c->pool, profile);
     stats.chains = c->nchains;
-
-    for (round = 0; round*c->nchains < c->ngops; round++)
+    for (g = 0; g < c->ngops; g++)
     {
-        const int g0 = round*c->nchains, ng = imin(c->nchains, c->ngops - g0);
-        stats.rounds++;
-        t0 = now_ms();
-        for (k = 0; k < ng; k++) if (h264e_hip_reset_results(c->pool, k)) goto done;
-        /* every chain speculates the mv_clusters state in front of this round (it rarely moves) */
-        const int32_t spec[2] = { clusters[0], clusters[1] };
-        for (f = 0; f < G; f++)
-        {
-            int any = 0;
-            for (k = 0; k < c->nchains; k++)
-            {
-                h264e_hip_task_t *t = tasks + k;
-                const int g = g0 + k, fi = g*G + f;
-                memset(t, 0, sizeof(*t));
-                if (k >= ng || fi >= c->nframes) continue;
-                any = 1;
-                t->active = 1; t->frame_index = fi; t->frame_slot = f;
-                t->slice_type = f ? SLICE_P : SLICE_I;
-                t->qp = qp; t->speed = c->par.speed;
-                /* idr_pic_id toggles with every key frame (h264-lab.h:6774): GOP g sees state ^ (g + 1 odd) */
-                slice_header_bits(&c->seq, !f, f, (idr_state ^ ((g + 1) & 1)), qp, pic_init_qp, no_deblock, &t->hdr_bits, &t->hdr_nbits);
-                t->mv_clusters[0] = clusters[0]; t->mv_clusters[1] = clusters[1];
-                memcpy(t->qdat, f ? qdat_p : qdat_i, sizeof(t->qdat));
-            }
-            if (any && h264e_hip_submit(c->pool, tasks)) goto done;
-        }
-        if (h264e_hip_sync(c->pool)) goto done;
-        stats.encode_ms += now_ms() - t0;
+        gops[g].nf = imin(G, c->nframes - g*G);
+        gops[g].in_state[0] = c->par.mv_clusters_in[0]; gops[g].in_state[1] = c->par.mv_clusters_in[1];   /* first guess: nothing moves */
+    }
 
-        for (k = 0; k < ng; k++)
+    while (first_open < c->ngops)
+    {
+        /* ---- pick the next GOPs that still need encoding, one per chain */
+        int ng = 0;
+        for (g = first_open; g < c->ngops && ng < c->nchains; g++)
+            if (!gops[g].encoded) sel[ng++] = g;
+        if (ng)
         {
-            const int g = g0 + k, nf = imin(G, c->nframes - g*G);
-            uint32_t used = 0;
-            int moved = 0, redo_from = -1;
+            stats.rounds++;
             t0 = now_ms();
-            if (h264e_hip_read_chain(c->pool, k, nf, res, offs, arena, arena_cap, &used)) goto done;
+            for (k = 0; k < ng; k++)
+            {
+                gop_t *q = gops + sel[k];
+                const int nf = q->nf;
+                int32_t keep[2] = { q->in_state[0], q->in_state[1] };
+                gop_free(q);
+                q->nf = nf; q->in_state[0] = keep[0]; q->in_state[1] = keep[1];
+                q->used_const = (int32_t (*)[2])calloc((size_t)nf, sizeof(int32_t[2]));
+                q->used_arr = (int32_t **)calloc((size_t)nf, sizeof(int32_t *));
+                q->off = (uint32_t *)calloc((size_t)nf, sizeof(uint32_t));
+                q->len = (uint32_t *)calloc((size_t)nf, sizeof(uint32_t));
+                if (!q->used_const || !q->used_arr || !q->off || !q->len) goto done;
+                run[k][0] = keep[0]; run[k][1] = keep[1];
+                if (h264e_hip_reset_results(c->pool, k)) goto done;
+            }
+            for (f = 0; f < G; f++)
+            {
+                int any = 0;
+                memset(tasks, 0, sizeof(*tasks)*(size_t)c->nchains);
+                for (k = 0; k < ng; k++)
+                {
+                    h264e_hip_task_t *t = tasks + k;
+                    gop_t *q = gops + sel[k];
+                    if (f >= q->nf) continue;
+                    any = 1;
+                    t->active = 1; t->frame_index = sel[k]*G + f; t->frame_slot = f;
+                    t->slice_type = f ? SLICE_P : SLICE_I;
+                    t->qp = qp; t->speed = c->par.speed;
+                    /* idr_pic_id toggles with every key frame (h264-lab.h:6774) */
+                    slice_header_bits(&c->seq, !f, f, (idr_state ^ ((sel[k] + 1) & 1)), qp, pic_init_qp, no_deblock, &t->hdr_bits, &t->hdr_nbits);
+                    t->mv_clusters[0] = run[k][0]; t->mv_clusters[1] = run[k][1];
+                    q->used_const[f][0] = run[k][0]; q->used_const[f][1] = run[k][1];
+                    memcpy(t->qdat, f ? qdat_p : qdat_i, sizeof(t->qdat));
+                }
+                if (!any) break;
+                {
+                    int extra = 0;
+                    memset(arrs, 0, sizeof(int32_t *)*(size_t)c->nchains);
+                    if (step_exact(c->pool, c->nchains, tasks, nmb, run, arrs, &extra)) goto done;
+                    stats.reencoded_gops += extra;          /* counts extra launches (exact passes) + re-encoded GOPs */
+                    for (k = 0; k < ng; k++)
+                        if (f < gops[sel[k]].nf) gops[sel[k]].used_arr[f] = arrs[k]; else free(arrs[k]);
+                }
+            }
+            stats.encode_ms += now_ms() - t0;
+            t0 = now_ms();
+            for (k = 0; k < ng; k++)
+            {
+                gop_t *q = gops + sel[k];
+                uint32_t used = 0;
+                if (h264e_hip_read_chain(c->pool, k, q->nf, res, q->off, arena, arena_cap, &used)) goto done;
+                q->rbsp = (uint8_t *)malloc(used ? used : 1);
+                q->rec = (h264e_hip_mbrec_t *)malloc(sizeof(h264e_hip_mbrec_t)*(size_t)nmb*(size_t)q->nf);
+                if (!q->rbsp || !q->rec) goto done;
+                memcpy(q->rbsp, arena, used);
+                q->rbsp_bytes = used;
+                for (f = 0; f < q->nf; f++) q->len[f] = res[f].nbytes;
+                if (h264e_hip_read_mbrec_all(c->pool, k, q->nf, q->rec)) goto done;
+                q->out_state[0] = run[k][0]; q->out_state[1] = run[k][1];
+                q->encoded = 1;
+            }
             stats.readback_ms += now_ms() - t0;
-            for (f = 0; f < nf; f++)
+        }
+
+        /* ---- validate in stream order; predict better input states for what has to be redone */
+        {
+            int32_t state[2], exact = 1;
+            if (first_open == 0) { state[0] = c->par.mv_clusters_in[0]; state[1] = c->par.mv_clusters_in[1]; }
+            else { state[0] = gops[first_open - 1].true_out[0]; state[1] = gops[first_open - 1].true_out[1]; }
+            for (g = first_open; g < c->ngops; g++)
             {
-                if (res[f].overflow) { snprintf(g_host_err, sizeof(g_host_err), "bit buffer overflow (GOP %d frame %d)", g, f); goto done; }
-                moved |= res[f].clusters_moved;
-            }
-            if (moved || clusters[0] != spec[0] || clusters[1] != spec[1])
-            {
-                /* exact validation: walk the true trajectory through the GOP's records */
-                int32_t cc[2] = { clusters[0], clusters[1] };
-                if (!rec) rec = (h264e_hip_mbrec_t *)malloc(sizeof(*rec)*(size_t)nmb);
-                if (!rec) goto done;
-                for (f = 0; f < nf && redo_from < 0; f++)
+                gop_t *q = gops + g;
+                int32_t o[2];
+                if (!q->encoded)
                 {
-                    int32_t before[2] = { cc[0], cc[1] };
-                    if (h264e_hip_read_mbrec(c->pool, k, f, rec)) goto done;
-                    if (clusters_walk(cc, rec, nmb, spec, 0, NULL) >= 0)
-                    {
-                        redo_from = f;
-                        cc[0] = before[0]; cc[1] = before[1];
-                    }
+                    /* not encoded yet: start it from the best prediction we have */
+                    q->in_state[0] = state[0]; q->in_state[1] = state[1];
+                    exact = 0;
+                    continue;
                 }
-                if (redo_from < 0) { clusters[0] = cc[0]; clusters[1] = cc[1]; }
-                else
+                if (gop_check(q, nmb, state, o))
                 {
-                    /* a consumed candidate differs: re-encode this GOP frame by frame with exact values.  Frames
-                     * before redo_from are valid, but the chain's pictures have moved on, so restart at its key frame. */
-                    int32_t ce[2] = { clusters[0], clusters[1] };
-                    stats.reencoded_gops++;
-                    if (h264e_hip_reset_results(c->pool, k)) goto done;
-                    for (f = 0; f < nf; f++)
-                    {
-                        h264e_hip_task_t t;
-                        h264e_hip_result_t r1;
-                        memset(&t, 0, sizeof(t));
-                        t.active = 1; t.frame_index = g*G + f; t.frame_slot = f;
-                        t.slice_type = f ? SLICE_P : SLICE_I; t.qp = qp; t.speed = c->par.speed;
-                        slice_header_bits(&c->seq, !f, f, (idr_state ^ ((g + 1) & 1)), qp, pic_init_qp, no_deblock, &t.hdr_bits, &t.hdr_nbits);
-                        memcpy(t.qdat, f ? qdat_p : qdat_i, sizeof(t.qdat));
-                        if (encode_frame_exact(c->pool, c->nchains, k, &t, nmb, ce, &r1, NULL)) goto done;
-                    }
-                    clusters[0] = ce[0]; clusters[1] = ce[1];
-                    if (h264e_hip_read_chain(c->pool, k, nf, res, offs, arena, arena_cap, &used)) goto done;
-                    /* re-encoded frames appended their results behind the stale ones: the slot table points at the fresh ones */
+                    q->encoded = 0;                 /* consumed candidates differ: encode again from `state` */
+                    q->in_state[0] = state[0]; q->in_state[1] = state[1];
+                    if (exact) stats.reencoded_gops++;
+                    exact = 0;
+                    /* keep walking with the stale records: still the best prediction for the GOPs behind it */
+                } else if (exact)
+                {
+                    q->valid = 1;
+                    q->true_out[0] = o[0]; q->true_out[1] = o[1];
+                    first_open = g + 1;
                 }
+                state[0] = o[0]; state[1] = o[1];
             }
-            t0 = now_ms();
-            for (f = 0; f < nf; f++)
-            {
-                const uint8_t *rb = arena + offs[f];
-                size_t start = pos, need = nal_escaped_size(rb, res[f].nbytes) + (f ? 0 : 64);
-                if (pos + need > cap) { snprintf(g_host_err, sizeof(g_host_err), "output buffer too small"); goto done; }
-                if (!f) pos += write_sps_pps(&c->seq, pic_init_qp, out + pos);
-                pos += nal_emit(out + pos, rb, res[f].nbytes);
-                if (frame_bytes) frame_bytes[g*G + f] = (int)(pos - start);
-            }
-            stats.assemble_ms += now_ms() - t0;
+            if (getenv("H264E_DEBUG")) fprintf(stderr, "clip round %d: encoded %d GOPs, valid prefix %d/%d\n", stats.rounds, ng, first_open, c->ngops);
         }
     }
-    stats.mv_clusters_out[0] = clusters[0]; stats.mv_clusters_out[1] = clusters[1];
+
+    t0 = now_ms();
+    for (g = 0; g < c->ngops; g++)
+    {
+        gop_t *q = gops + g;
+        for (f = 0; f < q->nf; f++)
+        {
+            const uint8_t *rb = q->rbsp + q->off[f];
+            size_t start = pos, need = nal_escaped_size(rb, q->len[f]) + (f ? 0 : 64);
+            if (pos + need > cap) { snprintf(g_host_err, sizeof(g_host_err), "output buffer too small"); goto done; }
+            if (!f) pos += write_sps_pps(&c->seq, pic_init_qp, out + pos);
+            pos += nal_emit(out + pos, rb, q->len[f]);
+            if (frame_bytes) frame_bytes[g*G + f] = (int)(pos - start);
+        }
+    }
+    stats.assemble_ms += now_ms() - t0;
+    stats.mv_clusters_out[0] = gops[c->ngops - 1].true_out[0]; stats.mv_clusters_out[1] = gops[c->ngops - 1].true_out[1];
     stats.next_idr_pic_id_state = idr_state ^ (c->ngops & 1);
     h264e_hip_profile_read(c->pool, &stats.mb_kernel_ms, &stats.splice_kernel_ms, &stats.kernel_launches);
     if (out_bytes) *out_bytes = pos;
     rc = 0;
 done:
     if (st) *st = stats;
-    free(tasks); free(res); free(offs); free(arena); free(rec);
+    if (gops) for (g = 0; g < c->ngops; g++) gop_free(gops + g);
+    free(tasks); free(res); free(gops); free(sel); free(flags); free(run); free(arena); free(arrs);
     return rc;
 }

@@ -91,11 +91,11 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
 }
 
 __global__ void __launch_bounds__(64) h264e_splice_kernel(h264e_geom_t G, const h264e_chain_dev_t *chains,
-                                                          const h264e_frame_task_t *tasks)
+                                                          const h264e_frame_task_t *tasks, int *stepflags)
 {
     const h264e_frame_task_t &T = tasks[blockIdx.x];
     if (!T.active) return;
-    finalize_frame(G, chains[blockIdx.x], T);
+    finalize_frame(G, chains[blockIdx.x], T, stepflags + 2*blockIdx.x);
 }
 
 #endif
@@ -170,6 +170,7 @@ struct h264e_hip_pool
     h264e_frame_task_t *tasks_dev;       /* ring of TASK_RING task arrays */
     int *progress_all;
     int *errflag;
+    int *stepflags;                      /* [nchains][2]: {clusters_moved, overflow} of the last step, one read per step */
     int32_t **clu_dev;                   /* per chain: optional per-macroblock mv_clusters array */
     int *ref_sel;                        /* per chain */
     int ring_pos, pending;
@@ -209,7 +210,7 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
             dev_free(C.mbrec); dev_free(C.arena); dev_free(C.cursor); dev_free(C.fout); dev_free(C.prof);
             if (p->clu_dev) dev_free(p->clu_dev[c]);
         }
-    dev_free(p->clip); dev_free(p->chains_dev); dev_free(p->tasks_dev); dev_free(p->progress_all); dev_free(p->errflag);
+    dev_free(p->clip); dev_free(p->chains_dev); dev_free(p->tasks_dev); dev_free(p->progress_all); dev_free(p->errflag); dev_free(p->stepflags);
 #ifndef H264E_EMU
     if (p->stream)
     {
@@ -260,6 +261,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     bad |= dev_malloc((void **)&p->tasks_dev, sizeof(h264e_frame_task_t)*(size_t)nchains*TASK_RING);
     bad |= dev_malloc((void **)&p->progress_all, sizeof(int)*(size_t)nchains*G.nmby);
     bad |= dev_malloc((void **)&p->errflag, sizeof(int));
+    bad |= dev_malloc((void **)&p->stepflags, sizeof(int)*2*(size_t)nchains);
     const size_t plane = (size_t)G.W*G.H*3/2;
     const uint32_t arena_cap = (uint32_t)((size_t)slots*((size_t)G.nmb*640 + 1024));
     for (int c = 0; c < nchains && !bad; c++)
@@ -450,7 +452,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             row_end(*L, G, C, row);
             free(L);
         }
-        finalize_frame(G, C, T);
+        finalize_frame(G, C, T, p->stepflags + 2*c);
     }
 #else
     HIPCHK(hipSetDevice(p->device));
@@ -465,13 +467,25 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
                        G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, p->nchains, p->errflag);
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][1], p->stream));
     hipLaunchKernelGGL(h264e_splice_kernel, dim3((unsigned)p->nchains), dim3(64), 0, p->stream,
-                       G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot);
+                       G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, p->stepflags);
     HIPCHK(hipGetLastError());
     if (p->profile)
     {
         HIPCHK(hipEventRecord(p->ev[pe][2], p->stream));
         p->ev_pending++;
     }
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_step_flags(h264e_hip_pool_t *p, int *flags /* [nchains][2] */)
+{
+    if (!p || !flags) FAIL("step_flags: bad argument");
+#ifdef H264E_EMU
+    memcpy(flags, p->stepflags, sizeof(int)*2*(size_t)p->nchains);
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpy(flags, p->stepflags, sizeof(int)*2*(size_t)p->nchains, hipMemcpyDeviceToHost));
 #endif
     return 0;
 }
@@ -551,6 +565,19 @@ extern "C" int h264e_hip_read_mbrec(h264e_hip_pool_t *p, int chain, int slot, h2
 #else
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipMemcpy(dst, p->chains_host[chain].mbrec + (size_t)slot*p->G.nmb, n, hipMemcpyDeviceToHost));
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_read_mbrec_all(h264e_hip_pool_t *p, int chain, int nslots, h264e_hip_mbrec_t *dst)
+{
+    if (!p || !dst || chain < 0 || chain >= p->nchains || nslots < 0 || nslots > p->slots) FAIL("read_mbrec_all: bad argument");
+    const size_t n = sizeof(h264e_mbrec_t)*(size_t)p->G.nmb*(size_t)nslots;
+#ifdef H264E_EMU
+    memcpy(dst, p->chains_host[chain].mbrec, n);
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpy(dst, p->chains_host[chain].mbrec, n, hipMemcpyDeviceToHost));
 #endif
     return 0;
 }

@@ -18,7 +18,9 @@
 #include <stdint.h>
 #include <string.h>
 
+/* explicit address spaces: HBM pointers that were loaded from memory would otherwise be generic (FLAT instructions) */
 #ifdef H264E_EMU
+#define GLOBAL_AS
 #define DEV static inline
 #define DCONST static const
 #ifdef H264E_EMU_REVERSE      /* run lanes in the opposite order: catches code that leaks a lane-private value */
@@ -46,6 +48,17 @@ template <class F> DEV void wave_sum4(F f, int out[4])
         for (int k = 0; k < 4; ++k) out[k] += v[k];
     }
 }
+/* eight sums at once: f(lane, v[8]) */
+template <class F> DEV void wave_sum8(F f, int out[8])
+{
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    for (int l = 0; l < 64; ++l)
+    {
+        int v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        f(l, v);
+        for (int k = 0; k < 8; ++k) out[k] += v[k];
+    }
+}
 template <class F> DEV uint64_t wave_ballot(F f)
 {
     uint64_t m = 0;
@@ -67,6 +80,7 @@ DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 #else /* device build */
 
 #include <hip/hip_runtime.h>
+#define GLOBAL_AS __attribute__((address_space(1)))
 #define DEV static __device__ __forceinline__
 #define DCONST static __device__ const
 #define WAVE_FOR(l) for (int l = (int)threadIdx.x, _w1 = 1; _w1; _w1 = 0)
@@ -103,6 +117,17 @@ template <class F> DEV void wave_sum4(F f, int out[4])
     out[0] = a & 0xffff; out[1] = (int)((unsigned)a >> 16);
     out[2] = b & 0xffff; out[3] = (int)((unsigned)b >> 16);
 }
+template <class F> DEV void wave_sum8(F f, int out[8])
+{
+    int v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    f((int)threadIdx.x, v);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        int a = wave_reduce_add(v[2*k] | (v[2*k + 1] << 16));      /* sums stay below 2^16 for every caller */
+        out[2*k] = a & 0xffff; out[2*k + 1] = (int)((unsigned)a >> 16);
+    }
+}
 template <class F> DEV uint64_t wave_ballot(F f) { return __ballot(f((int)threadIdx.x)); }
 DEV uint32_t sad4_u8(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
 DEV int clz32(uint32_t v) { return __clz((int)v); }
@@ -115,6 +140,13 @@ DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 #else
 #define STAMP(L, id) do { } while (0)
 #endif
+
+typedef GLOBAL_AS uint8_t gu8;                        /* a byte in HBM */
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef GLOBAL_AS u32_unaligned gu32u;
+
+DEV uint32_t gload32(const gu8 *p) { return *(const gu32u *)p; }
+DEV void gstore32(gu8 *p, uint32_t v) { *(gu32u *)p = v; }
 
 DEV int imin(int a, int b) { return a < b ? a : b; }
 DEV int imax(int a, int b) { return a > b ? a : b; }

@@ -61,12 +61,16 @@ int  h264e_hip_upload_planes(h264e_hip_pool_t *pool, int index, const uint8_t *c
 int  h264e_hip_generate_synth(h264e_hip_pool_t *pool, int first, int nframes, int t0, uint32_t seed);
 int  h264e_hip_submit(h264e_hip_pool_t *pool, const h264e_hip_task_t *tasks /* [nchains] */);
 int  h264e_hip_sync(h264e_hip_pool_t *pool);
+/* {clusters_moved, overflow} of every chain for the LAST submitted step, in one copy (call after h264e_hip_sync) */
+int  h264e_hip_step_flags(h264e_hip_pool_t *pool, int *flags /* [nchains][2] */);
 int  h264e_hip_result(h264e_hip_pool_t *pool, int chain, int slot, h264e_hip_result_t *res);
 int  h264e_hip_read_rbsp(h264e_hip_pool_t *pool, int chain, int slot, uint8_t *dst, uint32_t cap);
 /* all results of a chain in two copies: per-slot result + byte offset into arena_dst, which receives the used part of the arena */
 int  h264e_hip_read_chain(h264e_hip_pool_t *pool, int chain, int nslots, h264e_hip_result_t *res, uint32_t *offsets,
                           uint8_t *arena_dst, uint32_t cap, uint32_t *used);
 int  h264e_hip_read_mbrec(h264e_hip_pool_t *pool, int chain, int slot, h264e_hip_mbrec_t *dst /* [nmb] */);
+/* records of slots 0..nslots-1 in one copy, dst[nslots][nmb] */
+int  h264e_hip_read_mbrec_all(h264e_hip_pool_t *pool, int chain, int nslots, h264e_hip_mbrec_t *dst);
 /* reconstructed picture of the chain's last frame, coded size, packed I420 */
 int  h264e_hip_read_recon(h264e_hip_pool_t *pool, int chain, uint8_t *dst);
 /* forget the results of a chain (arena cursor back to 0); the reference picture is kept */
