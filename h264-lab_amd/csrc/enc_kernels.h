@@ -80,29 +80,35 @@ DEV uint32_t bw_bits(const BitW &b) { return b.pos*32u + (uint32_t)b.nacc; }
 
 struct Plane { const gu8 *p; int w, h, stride; };
 
-/* four samples (x..x+3, y), little-endian packed, coordinates clamped to the picture: this IS the
+/* clamped per-byte path of ref_load4: only picture borders get here, kept out of line */
+NOINLINE_DEV uint32_t ref_load4_border(const gu8 *row, int w, int x)
+{
+    uint32_t v = 0;
+    for (int k = 0; k < 4; k++) v |= (uint32_t)row[imin(imax(x + k, 0), w - 1)] << (8*k);
+    return v;
+}
+
+/* four samples (x..x+3, y) from HBM, little-endian packed, coordinates clamped to the picture: this IS the
  * reference's border extension (H:2232-2248) without storing the border */
 DEV uint32_t ref_load4(const Plane &P, int x, int y)
 {
     y = imin(imax(y, 0), P.h - 1);
     const gu8 *r = P.p + (size_t)y*P.stride;
-    if (x >= 0 && x + 3 < P.w) return *(const gu32u *)(r + x);
-    uint32_t v = 0;
-    for (int k = 0; k < 4; k++) v |= (uint32_t)r[imin(imax(x + k, 0), P.w - 1)] << (8*k);
-    return v;
+    if (x >= 0 && x + 3 < P.w) return gload32(r + x);
+    return ref_load4_border(r, P.w, x);
 }
 
 DEV uint32_t lds32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 DEV void lds32_store(uint8_t *p, uint32_t v) { memcpy(p, &v, 4); }
 
 /* 4 bytes at an arbitrary LDS byte address: two aligned dword reads + v_alignbyte */
-DEV uint32_t lds32u(const uint8_t *p)
+DEV uint32_t lds32u(const lu8 *p)
 {
 #ifdef H264E_EMU
     uint32_t v; memcpy(&v, p, 4); return v;
 #else
     const uint32_t a = (uint32_t)(uintptr_t)p;
-    const uint32_t *q = (const uint32_t *)(p - (a & 3));
+    const LDS_AS uint32_t *q = (const LDS_AS uint32_t *)(p - (a & 3));
     return __builtin_amdgcn_alignbyte(q[1], q[0], a & 3);
 #endif
 }
@@ -110,19 +116,20 @@ DEV uint32_t lds32u(const uint8_t *p)
 /*
  * Reference luma through an LDS-staged window: WIN_W x WIN_W samples around the current macroblock
  * (WIN_M samples of margin on every side), loaded once per macroblock with clamped coordinates.
- * Accesses outside the window (long vectors) fall back to HBM.
+ * A block whose whole footprint lies inside the window is served from LDS without per-access checks;
+ * anything else (long vectors) reads HBM.
  */
 #define WIN_M 24
 #define WIN_W 64
 #define WIN_STRIDE 68       /* 17 dwords: consecutive rows start on different LDS banks */
-struct RefView { Plane P; const uint8_t *win; int has_win, wx0, wy0; };   /* win always points at the LDS window */
+struct RefView { Plane P; const lu8 *win; int has_win, wx0, wy0; };
 
-DEV uint32_t rv_load4(const RefView &V, int x, int y)
+/* wave-uniform: does the sample rectangle [x0,x1] x [y0,y1] lie inside the window? */
+DEV bool rv_inside(const RefView &V, int x0, int y0, int x1, int y1)
 {
-    const int lx = x - V.wx0, ly = y - V.wy0;
-    if (V.has_win && (unsigned)lx <= (unsigned)(WIN_W - 4) && (unsigned)ly < (unsigned)WIN_W) return lds32u(V.win + ly*WIN_STRIDE + lx);
-    return ref_load4(V.P, x, y);
+    return V.has_win && x0 >= V.wx0 && y0 >= V.wy0 && x1 < V.wx0 + WIN_W && y1 < V.wy0 + WIN_W;
 }
+DEV const lu8 *rv_ptr(const RefView &V, int x, int y) { return V.win + (y - V.wy0)*WIN_STRIDE + (x - V.wx0); }
 
 /* one lane per window row, 16 dword loads in flight per lane */
 DEV void wave_load_window(uint8_t *win, const Plane &P, int wx0, int wy0)
@@ -144,20 +151,39 @@ DEV void wave_load_window(uint8_t *win, const Plane &P, int wx0, int wy0)
 DEV int wave_sad_ref(const RefView &R, int x0, int y0, const uint8_t *b, int w, int h)
 {
     const int g = w >> 2, n = g*h;
+    if (rv_inside(R, x0, y0, x0 + w - 1, y0 + h - 1))
+    {
+        const lu8 *base = rv_ptr(R, x0, y0);
+        return wave_sum([&](int l) -> int {
+            if (l >= n) return 0;
+            int r = l/g, c = l - r*g;
+            return (int)sad4_u8(lds32u(base + r*WIN_STRIDE + 4*c), lds32(b + 16*r + 4*c), 0);
+        });
+    }
     return wave_sum([&](int l) -> int {
         if (l >= n) return 0;
         int r = l/g, c = l - r*g;
-        return (int)sad4_u8(rv_load4(R, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
+        return (int)sad4_u8(ref_load4(R.P, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
     });
 }
 
 /* 16x16 SAD with the four 8x8 quadrant sums (H:2178-2187) */
 DEV int wave_sad_ref_q(const RefView &R, int x0, int y0, const uint8_t *b, int sad4[4])
 {
-    wave_sum4([&](int l, int *v) {
-        int r = l >> 2, c = l & 3;
-        v[(r >> 3)*2 + (c >> 1)] = (int)sad4_u8(rv_load4(R, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
-    }, sad4);
+    if (rv_inside(R, x0, y0, x0 + 15, y0 + 15))
+    {
+        const lu8 *base = rv_ptr(R, x0, y0);
+        wave_sum4([&](int l, int *v) {
+            int r = l >> 2, c = l & 3;
+            v[(r >> 3)*2 + (c >> 1)] = (int)sad4_u8(lds32u(base + r*WIN_STRIDE + 4*c), lds32(b + 16*r + 4*c), 0);
+        }, sad4);
+    } else
+    {
+        wave_sum4([&](int l, int *v) {
+            int r = l >> 2, c = l & 3;
+            v[(r >> 3)*2 + (c >> 1)] = (int)sad4_u8(ref_load4(R.P, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
+        }, sad4);
+    }
     return sad4[0] + sad4[1] + sad4[2] + sad4[3];
 }
 
@@ -185,20 +211,20 @@ DEV int wave_sad_lds_q(const uint8_t *a, const uint8_t *b, int sad4[4])
 DEV int tap6(int a, int b, int c, int d, int e, int f) { return a - 5*b + 20*c + 20*d - 5*e + f; }
 
 /*
- * Standard H.264 quarter-sample luma interpolation (H:2079-2131) of the 4 samples starting at integer
- * position (x,y), fraction (fx,fy): half samples from the 6-tap filter, quarter samples as rounded
- * averages of the two nearest integer/half samples.  Everything is unrolled over compile-time indices so
- * the tap arrays live in registers; the position dispatch is wave-uniform.
+ * Standard H.264 quarter-sample luma interpolation (H:2079-2131) of 4 adjacent samples, fraction (fx,fy): half
+ * samples from the 6-tap filter, quarter samples as rounded averages of the two nearest integer/half samples.
+ * ld(dx, dy) returns the 4 reference samples at (x + dx .. x + dx + 3, y + dy).  Everything is unrolled over
+ * compile-time indices so the tap arrays live in registers; the position dispatch is wave-uniform.
  */
-DEV uint32_t interp_luma4(const RefView &R, int x, int y, int fx, int fy)
+template <class LD> DEV uint32_t interp_core(LD ld, int fx, int fy)
 {
-    if (!(fx | fy)) return rv_load4(R, x, y);
+    if (!(fx | fy)) return ld(0, 0);
     const int pos = fx + 4*fy;
     int A[4], B[4];
     bool avg = true;
     if (fy == 0)
     {
-        const uint32_t a = rv_load4(R, x - 4, y), b = rv_load4(R, x, y), c = rv_load4(R, x + 4, y);
+        const uint32_t a = ld(-4, 0), b = ld(0, 0), c = ld(4, 0);
         int p[12];
 #pragma unroll
         for (int k = 0; k < 4; k++) { p[k] = (int)((a >> (8*k)) & 255); p[4 + k] = (int)((b >> (8*k)) & 255); p[8 + k] = (int)((c >> (8*k)) & 255); }
@@ -208,19 +234,32 @@ DEV uint32_t interp_luma4(const RefView &R, int x, int y, int fx, int fy)
             B[i] = clip255((tap6(p[i + 2], p[i + 3], p[i + 4], p[i + 5], p[i + 6], p[i + 7]) + 16) >> 5);
             A[i] = pos == 3 ? p[5 + i] : p[4 + i];
         }
-        if (pos == 2) avg = false;
-        if (!avg) { A[0] = B[0]; A[1] = B[1]; A[2] = B[2]; A[3] = B[3]; }
+        if (pos == 2) { avg = false; A[0] = B[0]; A[1] = B[1]; A[2] = B[2]; A[3] = B[3]; }
+    } else if (fx == 0)
+    {
+        /* vertical only: d h n */
+        int cb[6][4];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+        {
+            const uint32_t b = ld(0, r - 2);
+#pragma unroll
+            for (int k = 0; k < 4; k++) cb[r][k] = (int)((b >> (8*k)) & 255);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            A[i] = clip255((tap6(cb[0][i], cb[1][i], cb[2][i], cb[3][i], cb[4][i], cb[5][i]) + 16) >> 5);
+            B[i] = fy == 3 ? cb[3][i] : cb[2][i];
+        }
+        if (fy == 2) avg = false;
     } else
     {
-        const bool need_h = fx != 0;        /* horizontal taps (b, s, j) */
         int th[6][4], cb[6][5];
 #pragma unroll
         for (int r = 0; r < 6; r++)
         {
-            const uint32_t b = rv_load4(R, x, y + r - 2);
-            uint32_t a = 0, c = 0;
-            if (need_h) { a = rv_load4(R, x - 4, y + r - 2); }
-            c = rv_load4(R, x + 4, y + r - 2);
+            const uint32_t a = ld(-4, r - 2), b = ld(0, r - 2), c = ld(4, r - 2);
             int p[12];
 #pragma unroll
             for (int k = 0; k < 4; k++) { p[k] = (int)((a >> (8*k)) & 255); p[4 + k] = (int)((b >> (8*k)) & 255); p[8 + k] = (int)((c >> (8*k)) & 255); }
@@ -237,13 +276,11 @@ DEV uint32_t interp_luma4(const RefView &R, int x, int y, int fx, int fy)
                               : clip255((tap6(cb[0][i], cb[1][i], cb[2][i], cb[3][i], cb[4][i], cb[5][i]) + 16) >> 5);
             const int hd = clip255((tap6(th[0][i], th[1][i], th[2][i], th[3][i], th[4][i], th[5][i]) + 512) >> 10);
             const int hh = clip255(((fy == 3 ? th[3][i] : th[2][i]) + 16) >> 5);    /* b (row y) or s (row y+1) */
-            const int g = fy == 3 ? cb[3][i] : cb[2][i];                         /* integer sample G or the one below */
-            if (fx == 0)      { A[i] = hv; B[i] = g; }                         /* d h n */
-            else if (fx == 2) { A[i] = hd; B[i] = hh; }                        /* f j q */
+            if (fx == 2)      { A[i] = hd; B[i] = hh; }                        /* f j q */
             else if (fy == 2) { A[i] = hv; B[i] = hd; }                        /* i k */
             else              { A[i] = hh; B[i] = hv; }                        /* e g p r */
         }
-        if (fy == 2 && (fx == 0 || fx == 2)) avg = false;                      /* h, j */
+        if (fy == 2 && fx == 2) avg = false;                                   /* j */
     }
     uint32_t out = 0;
 #pragma unroll
@@ -251,16 +288,40 @@ DEV uint32_t interp_luma4(const RefView &R, int x, int y, int fx, int fy)
     return out;
 }
 
+/* the two instantiations, out of line (one copy each in the kernel): from the LDS window, or from HBM with clamping */
+NOINLINE_DEV uint32_t interp4_win(const lu8 *at, int fx, int fy)
+{
+    return interp_core([&](int dx, int dy) -> uint32_t { return lds32u(at + dy*WIN_STRIDE + dx); }, fx, fy);
+}
+NOINLINE_DEV uint32_t interp4_hbm(const gu8 *p, int w, int h, int stride, int x, int y, int fx, int fy)
+{
+    Plane P; P.p = p; P.w = w; P.h = h; P.stride = stride;
+    return interp_core([&](int dx, int dy) -> uint32_t { return ref_load4(P, x + dx, y + dy); }, fx, fy);
+}
+
+/* 4 interpolated samples at integer position (x,y); `inside` (wave-uniform) says the block's footprint is in the window */
+DEV uint32_t interp_luma4(const RefView &R, bool inside, int x, int y, int fx, int fy)
+{
+    if (inside) return interp4_win(rv_ptr(R, x, y), fx, fy);
+    return interp4_hbm(R.P.p, R.P.w, R.P.h, R.P.stride, x, y, fx, fy);
+}
+/* footprint of a w x h block at integer position (ix,iy) for any fraction: 6-tap support plus the dword loads' slack */
+DEV bool rv_inside_interp(const RefView &R, int ix, int iy, int w, int h)
+{
+    return rv_inside(R, ix - 4, iy - 2, ix + w + 3, iy + h + 2);
+}
+
 /* H:4905-4910 interpolate_luma: w x h block whose top-left is (bx,by) + mv (absolute quarter-pel) -> LDS dst */
 DEV void wave_interp_luma(const RefView &R, int bx, int by, mv32 mv, int w, int h, uint8_t *dst)
 {
     const int g = w >> 2, n = g*h, ix = bx + (mvx(mv) >> 2), iy = by + (mvy(mv) >> 2), fx = mvx(mv) & 3, fy = mvy(mv) & 3;
+    const bool inside = rv_inside_interp(R, ix, iy, w, h);
     WAVE_FOR(l)
     {
         if (l < n)
         {
             int r = l/g, c = l - r*g;
-            lds32_store(dst + 16*r + 4*c, interp_luma4(R, ix + 4*c, iy + r, fx, fy));
+            lds32_store(dst + 16*r + 4*c, interp_luma4(R, inside, ix + 4*c, iy + r, fx, fy));
         }
     }
     wave_sync();
@@ -428,7 +489,7 @@ DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_
     wave_sync();
     int dc;
     {
-        const uint32_t lw = lds32(S.edge), tw = lds32u(S.edge + 5);
+        const uint32_t lw = lds32(S.edge), tw = lds32u((const lu8 *)(S.edge + 5));
         const int sl = (int)((lw & 255) + ((lw >> 8) & 255) + ((lw >> 16) & 255) + (lw >> 24));
         const int st = (int)((tw & 255) + ((tw >> 8) & 255) + ((tw >> 16) & 255) + (tw >> 24));
         const int hl = (avail & AV_L) != 0, ht = (avail & AV_T) != 0;

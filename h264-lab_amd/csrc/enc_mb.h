@@ -208,15 +208,31 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
                         if (in_rect(vd2, range) && CGET(cur, d) == 0xffffu) want |= 1 << d;
                     }
                     const int cx = px + (mvx(mv) >> 2), cy = py + (mvy(mv) >> 2);
-                    wave_sum4([&](int l, int *sv) {
-                        if (l >= n) return;
-                        const int r = l/g, c4 = l - r*g;
-                        const uint32_t in4 = lds32(b + 16*r + 4*c4);
-                        if (want & 1) sv[0] = (int)sad4_u8(rv_load4(R, cx + 4*c4 + 1, cy + r), in4, 0);
-                        if (want & 2) sv[1] = (int)sad4_u8(rv_load4(R, cx + 4*c4 - 1, cy + r), in4, 0);
-                        if (want & 4) sv[2] = (int)sad4_u8(rv_load4(R, cx + 4*c4, cy + r + 1), in4, 0);
-                        if (want & 8) sv[3] = (int)sad4_u8(rv_load4(R, cx + 4*c4, cy + r - 1), in4, 0);
-                    }, s4);
+                    if (rv_inside(R, cx - 1, cy - 1, cx + w, cy + h))
+                    {
+                        const lu8 *base = rv_ptr(R, cx, cy);
+                        wave_sum4([&](int l, int *sv) {
+                            if (l >= n) return;
+                            const int r = l/g, c4 = l - r*g;
+                            const uint32_t in4 = lds32(b + 16*r + 4*c4);
+                            const lu8 *p = base + r*WIN_STRIDE + 4*c4;
+                            if (want & 1) sv[0] = (int)sad4_u8(lds32u(p + 1), in4, 0);
+                            if (want & 2) sv[1] = (int)sad4_u8(lds32u(p - 1), in4, 0);
+                            if (want & 4) sv[2] = (int)sad4_u8(lds32u(p + WIN_STRIDE), in4, 0);
+                            if (want & 8) sv[3] = (int)sad4_u8(lds32u(p - WIN_STRIDE), in4, 0);
+                        }, s4);
+                    } else
+                    {
+                        wave_sum4([&](int l, int *sv) {
+                            if (l >= n) return;
+                            const int r = l/g, c4 = l - r*g;
+                            const uint32_t in4 = lds32(b + 16*r + 4*c4);
+                            if (want & 1) sv[0] = (int)sad4_u8(ref_load4(R.P, cx + 4*c4 + 1, cy + r), in4, 0);
+                            if (want & 2) sv[1] = (int)sad4_u8(ref_load4(R.P, cx + 4*c4 - 1, cy + r), in4, 0);
+                            if (want & 4) sv[2] = (int)sad4_u8(ref_load4(R.P, cx + 4*c4, cy + r + 1), in4, 0);
+                            if (want & 8) sv[3] = (int)sad4_u8(ref_load4(R.P, cx + 4*c4, cy + r - 1), in4, 0);
+                        }, s4);
+                    }
                     bs0 = s4[0]; bs1 = s4[1]; bs2 = s4[2]; bs3 = s4[3];
                     have = want;
                 }
@@ -281,11 +297,13 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
         const mv32 v02 = mvadd(mv, mvadd(pq, pq)), v01 = mvadd(mv, pq), v20 = mvadd(mv, mvadd(sq, sq)), v10 = mvadd(mv, sq);
         const mv32 v11 = mvadd(mv, vdg), v22 = mvadd(mv, mvadd(vdg, vdg)), v12 = mvadd(mv, mvadd(pq, vdg));
         int s8[8];
+        const int fx0 = px + (mvx(mv) >> 2), fy0 = py + (mvy(mv) >> 2);
+        const bool inside = rv_inside(R, fx0 - 5, fy0 - 3, fx0 + w + 4, fy0 + h + 3);      /* every probe is within one sample of mv */
         wave_sum8([&](int l, int *sv) {
             if (l >= n) return;
             const int r = l/g, c4 = l - r*g, o = 16*r + 4*c4;
             const uint32_t in4 = lds32(b + o);
-#define IP(vv) interp_luma4(R, px + (mvx(vv) >> 2) + 4*c4, py + (mvy(vv) >> 2) + r, mvx(vv) & 3, mvy(vv) & 3)
+#define IP(vv) interp_luma4(R, inside, px + (mvx(vv) >> 2) + 4*c4, py + (mvy(vv) >> 2) + r, mvx(vv) & 3, mvy(vv) & 3)
 #define AVG4(x, y) (((x) | (y)) - ((((x) ^ (y)) >> 1) & 0x7f7f7f7fu))                    /* per-byte (x + y + 1) >> 1 */
             const uint32_t q00 = IP(mv), q02 = IP(v02), q20 = IP(v20), q22 = IP(v22);
 #undef IP

@@ -118,7 +118,7 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
     STAMP(L, 0);
     load_top(L, G, rowrec - G.nmbx, x, row > 0);
     load_input(L, G, T, x, row);
-    m.rv.P = m.ref[0]; m.rv.win = L.win; m.rv.has_win = 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
+    m.rv.P = m.ref[0]; m.rv.win = (const lu8 *)L.win; m.rv.has_win = 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
     if (T.slice_type == 0)
     {
         wave_load_window(L.win, m.ref[0], m.rv.wx0, m.rv.wy0);

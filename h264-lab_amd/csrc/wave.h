@@ -21,6 +21,8 @@
 /* explicit address spaces: HBM pointers that were loaded from memory would otherwise be generic (FLAT instructions) */
 #ifdef H264E_EMU
 #define GLOBAL_AS
+#define LDS_AS
+#define NOINLINE_DEV static __attribute__((noinline))
 #define DEV static inline
 #define DCONST static const
 #ifdef H264E_EMU_REVERSE      /* run lanes in the opposite order: catches code that leaks a lane-private value */
@@ -81,6 +83,8 @@ DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
 #include <hip/hip_runtime.h>
 #define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+#define NOINLINE_DEV static __device__ __noinline__
 #define DEV static __device__ __forceinline__
 #define DCONST static __device__ const
 #define WAVE_FOR(l) for (int l = (int)threadIdx.x, _w1 = 1; _w1; _w1 = 0)
@@ -141,6 +145,7 @@ DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 #define STAMP(L, id) do { } while (0)
 #endif
 
+typedef LDS_AS uint8_t lu8;                           /* a byte in LDS (explicit, so out-of-line functions keep ds_* instructions) */
 typedef GLOBAL_AS uint8_t gu8;                        /* a byte in HBM */
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef GLOBAL_AS u32_unaligned gu32u;
