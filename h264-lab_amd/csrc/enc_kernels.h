@@ -122,7 +122,12 @@ DEV uint32_t lds32u(const lu8 *p)
 #define WIN_M 24
 #define WIN_W 64
 #define WIN_STRIDE 68       /* 17 dwords: consecutive rows start on different LDS banks */
-struct RefView { Plane P; const lu8 *win; int has_win, wx0, wy0; };
+struct RefView
+{
+    Plane P; const lu8 *win; int has_win, wx0, wy0;
+    const int *dep;             /* progress counters of the frame being referenced while it is still being encoded (temporal wavefront) */
+    int nmbx, nmby;
+};
 
 /* wave-uniform: does the sample rectangle [x0,x1] x [y0,y1] lie inside the window? */
 DEV bool rv_inside(const RefView &V, int x0, int y0, int x1, int y1)
@@ -130,6 +135,34 @@ DEV bool rv_inside(const RefView &V, int x0, int y0, int x1, int y1)
     return V.has_win && x0 >= V.wx0 && y0 >= V.wy0 && x1 < V.wx0 + WIN_W && y1 < V.wy0 + WIN_W;
 }
 DEV const lu8 *rv_ptr(const RefView &V, int x, int y) { return V.win + (y - V.wy0)*WIN_STRIDE + (x - V.wx0); }
+
+/*
+ * Temporal wavefront: the reference picture may still be under construction by an earlier job of the same launch.
+ * The window region is covered by the static lag of the row loop; a read OUTSIDE it (long vector) first waits until
+ * the producing frame has finished -- reconstructed and deblocked -- the sample rectangle [x0,x1] x [y0,y1]:
+ * a sample of macroblock (X,Y) is final once row Y+1 has passed column X (its top-edge filter), which in wavefront
+ * order implies row Y passed X+2; on the last row, once row Y passed X+1.  Wave-uniform.
+ */
+DEV void rv_wait_rect(const RefView &V, int x1, int y1)
+{
+#ifndef H264E_EMU
+    if (!V.dep) return;
+    const int X = imin(imax(x1, 0), V.P.w - 1) >> 4, Y = imin(imax(y1, 0), V.P.h - 1) >> 4;
+    const int drow = imin(Y + 1, V.nmby - 1), need = imin(X + 2, V.nmbx);
+    const int *flag = V.dep + drow;
+    unsigned spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need)
+    {
+        if (++spins > (1u << 24)) break;            /* bounded: a stuck producer is reported by its own row loop */
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#else
+    (void)V; (void)x1; (void)y1;
+#endif
+}
 
 /* one lane per window row, 16 dword loads in flight per lane */
 DEV void wave_load_window(uint8_t *win, const Plane &P, int wx0, int wy0)
@@ -160,6 +193,7 @@ DEV int wave_sad_ref(const RefView &R, int x0, int y0, const uint8_t *b, int w, 
             return (int)sad4_u8(lds32u(base + r*WIN_STRIDE + 4*c), lds32(b + 16*r + 4*c), 0);
         });
     }
+    rv_wait_rect(R, x0 + w - 1, y0 + h - 1);
     return wave_sum([&](int l) -> int {
         if (l >= n) return 0;
         int r = l/g, c = l - r*g;
@@ -179,6 +213,7 @@ DEV int wave_sad_ref_q(const RefView &R, int x0, int y0, const uint8_t *b, int s
         }, sad4);
     } else
     {
+        rv_wait_rect(R, x0 + 15, y0 + 15);
         wave_sum4([&](int l, int *v) {
             int r = l >> 2, c = l & 3;
             v[(r >> 3)*2 + (c >> 1)] = (int)sad4_u8(ref_load4(R.P, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
@@ -316,6 +351,7 @@ DEV void wave_interp_luma(const RefView &R, int bx, int by, mv32 mv, int w, int 
 {
     const int g = w >> 2, n = g*h, ix = bx + (mvx(mv) >> 2), iy = by + (mvy(mv) >> 2), fx = mvx(mv) & 3, fy = mvy(mv) & 3;
     const bool inside = rv_inside_interp(R, ix, iy, w, h);
+    if (!inside) rv_wait_rect(R, ix + w + 3, iy + h + 2);
     WAVE_FOR(l)
     {
         if (l < n)
@@ -363,8 +399,12 @@ DEV void wave_copy_wh(uint8_t *d, const uint8_t *s, int w, int h)
  * (cx,cy) = partition position in the chroma plane, mv = LUMA vector (absolute quarter-pel), dst = U at
  * column 0, V at column 8 (stride 16), already offset to the partition.
  */
-DEV void wave_interp_chroma(const Plane &RU, const Plane &RV, int cx, int cy, mv32 mv, int w, int h, uint8_t *dst)
+DEV void wave_interp_chroma(const RefView &RL, const Plane &RU, const Plane &RV, int cx, int cy, mv32 mv, int w, int h, uint8_t *dst)
 {
+    {   /* luma-sample rectangle this chroma block corresponds to: inside the window it is covered by the row loop's lag */
+        const int lx0 = 2*(cx + (mvx(mv) >> 3)), ly0 = 2*(cy + (mvy(mv) >> 3));
+        if (!rv_inside(RL, lx0, ly0, lx0 + 2*w + 3, ly0 + 2*h + 3)) rv_wait_rect(RL, lx0 + 2*w + 3, ly0 + 2*h + 3);
+    }
     const int g = w >> 2, n = g*h, dx = mvx(mv) & 7, dy = mvy(mv) & 7;
     const int ix = cx + (mvx(mv) >> 3), iy = cy + (mvy(mv) >> 3);
     const int A = (8 - dx)*(8 - dy), B = dx*(8 - dy), C = (8 - dx)*dy, D = dx*dy;

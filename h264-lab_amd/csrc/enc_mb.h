@@ -223,6 +223,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
                         }, s4);
                     } else
                     {
+                        rv_wait_rect(R, cx + w, cy + h);
                         wave_sum4([&](int l, int *sv) {
                             if (l >= n) return;
                             const int r = l/g, c4 = l - r*g;
@@ -299,6 +300,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
         int s8[8];
         const int fx0 = px + (mvx(mv) >> 2), fy0 = py + (mvy(mv) >> 2);
         const bool inside = rv_inside(R, fx0 - 5, fy0 - 3, fx0 + w + 4, fy0 + h + 3);      /* every probe is within one sample of mv */
+        if (!inside) rv_wait_rect(R, fx0 + w + 4, fy0 + h + 3);
         wave_sum8([&](int l, int *sv) {
             if (l >= n) return;
             const int r = l/g, c4 = l - r*g, o = 16*r + 4*c4;
@@ -350,7 +352,7 @@ DEV void predict_chroma_inter(RowLds &L, const MbCtx &m)
     if (m.type == -1) w = h = 8;
     for (;; part++)
     {
-        wave_interp_chroma(m.ref[1], m.ref[2], x, y, mb_abs(m, L.mv[part]), w, h, L.pred_c + 16*y + x);
+        wave_interp_chroma(m.rv, m.ref[1], m.ref[2], x, y, mb_abs(m, L.mv[part]), w, h, L.pred_c + 16*y + x);
         x = (x + w) & 7;
         if (!x)
         {

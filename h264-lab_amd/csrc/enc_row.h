@@ -102,9 +102,9 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
     m.G = &G; m.T = &T;
     for (int c = 0; c < 3; c++)
     {
-        m.ref[c].p = (const gu8 *)C.rec[T.ref_sel][c];
+        m.ref[c].p = (const gu8 *)T.ref[c];
         m.ref[c].w = G.W >> (c ? 1 : 0); m.ref[c].h = G.H >> (c ? 1 : 0); m.ref[c].stride = m.ref[c].w;
-        m.dec[c] = (gu8 *)C.rec[T.ref_sel ^ 1][c];
+        m.dec[c] = (gu8 *)T.dec[c];
     }
     m.x = x; m.y = row; m.num = row*G.nmbx + x;
     m.avail = (row > 0 ? AV_T : 0) | (row > 0 && x != G.nmbx - 1 ? AV_TR : 0) | (x > 0 ? AV_L : 0) | (row > 0 && x > 0 ? AV_TL : 0);
@@ -118,6 +118,7 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
     STAMP(L, 0);
     load_top(L, G, rowrec - G.nmbx, x, row > 0);
     load_input(L, G, T, x, row);
+    m.rv.dep = T.dep_progress; m.rv.nmbx = G.nmbx; m.rv.nmby = G.nmby;
     m.rv.P = m.ref[0]; m.rv.win = (const lu8 *)L.win; m.rv.has_win = 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
     if (T.slice_type == 0)
     {
@@ -360,7 +361,7 @@ DEV void clusters_step(mv32 c[2], mv32 mv)                                  /* h
 DEV void finalize_frame(const h264e_geom_t &G, const h264e_chain_dev_t &C, const h264e_frame_task_t &T, int *stepflags)
 {
     SpliceState s;
-    const uint32_t start = (*C.cursor + 3u) & ~3u;
+    const uint32_t start = T.arena_reset ? 0u : ((*C.cursor + 3u) & ~3u);
     s.out = (uint32_t *)(C.arena + start);
     s.wpos = 0; s.carry = 0; s.cbits = 0; s.overflow = 0;
     s.cap_words = (C.arena_cap - start) >> 2;

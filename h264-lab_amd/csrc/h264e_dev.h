@@ -91,7 +91,11 @@ typedef struct
     int qp;
     int speed;
     int no_deblock;
-    int ref_sel;                        /* rec[ref_sel] is the reference, rec[ref_sel ^ 1] the picture being built */
+    int chain;                          /* which chain's row/record/result buffers this job uses */
+    const uint8_t *ref[3];              /* reference picture (coded size, stride = width); unused for I slices */
+    uint8_t *dec[3];                    /* picture being built */
+    int arena_reset;                    /* the result goes to the start of the chain's arena (one result per chain slot) */
+    const int *dep_progress;            /* progress counters of the job that builds `ref` in the SAME launch, or NULL when ref is complete */
     int frame_slot;
     int hdr_nbits;                      /* NAL header byte + slice header, MSB-aligned at bit hdr_nbits-1 */
     uint64_t hdr_bits;

@@ -684,13 +684,20 @@ int H264E_encode(H264E_persist_t *p, H264E_scratch_t *scratch, const H264E_run_p
     return H264E_STATUS_SUCCESS;
 }
 
-/* ------------------------------------------------------------------ whole-clip encode, GOPs as parallel chains */
+/* ------------------------------------------------------------------ whole-clip encode: temporal wavefront */
 
+/*
+ * The clip is ONE stream, encoded in stream order, but many consecutive frames are in flight at once: each frame is a
+ * job of the same launch and starts a few macroblock rows behind the frame it references (h264e_kernels.hip), key
+ * frames start immediately.  All frames of a launch speculate the mv_clusters state known when the launch starts;
+ * afterwards the host validates them in order (exact walk of the per-macroblock records) and relaunches from the
+ * first frame whose consumed candidates differ -- that frame with exact per-macroblock values.
+ */
 struct H264E_clip_tag
 {
     H264E_clip_param_t par;
     seq_t seq;
-    int nframes, ngops, nchains, gop_len;
+    int nframes, gop_len, ring;
     h264e_hip_pool_t *pool;
 };
 
@@ -704,6 +711,7 @@ static double now_ms(void)
 int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nframes)
 {
     H264E_clip_t *c;
+    int nmby, cap;
     g_host_err[0] = 0;
     if (!out || !par || nframes <= 0 || par->width <= 0 || par->height <= 0 || ((par->width | par->height) & 1) || par->gop < 0) return -1;
     c = (H264E_clip_t *)calloc(1, sizeof(*c));
@@ -713,9 +721,12 @@ int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nfram
     seq_init(&c->seq, par->width, par->height, par->vbv_size_bytes, 0);
     c->nframes = nframes;
     c->gop_len = par->gop ? par->gop : nframes;
-    c->ngops = (nframes + c->gop_len - 1)/c->gop_len;
-    c->nchains = par->max_chains > 0 ? imin(par->max_chains, c->ngops) : c->ngops;
-    if (h264e_hip_pool_create(&c->pool, par->device, par->width, par->height, c->nchains, nframes, c->gop_len))
+    /* frames in flight + 1: bounded by what the GPU keeps resident (2 waves/SIMD x 1024 SIMDs, one wave per macroblock row) */
+    nmby = (par->height + 15) >> 4;
+    cap = imax(2, 1800/nmby);
+    c->ring = par->max_chains > 0 ? par->max_chains + 1 : 17;
+    c->ring = imin(imin(c->ring, cap + 1), nframes + 1);
+    if (h264e_hip_pool_create(&c->pool, par->device, par->width, par->height, c->ring, nframes, 1))
     {
         free(c);
         return -1;
@@ -748,207 +759,109 @@ int H264E_clip_generate_synth(H264E_clip_t *c, int first, int nframes, int t0, u
 /* diagnostic (stamps build): per-phase cycle sums since the last call */
 int H264E_clip_stamps(H264E_clip_t *c, unsigned long long *dst) { return c ? h264e_hip_stamps_read(c->pool, dst, 1) : -1; }
 
-/*
- * One GOP of the clip encoder.  A GOP is encoded against an ASSUMED mv_clusters input state (the state in front
- * of its key frame); inside the GOP the state is tracked exactly, frame by frame.  After all earlier GOPs are
- * known, the GOP is valid if the candidates it consumed equal the ones the true input state gives.
- */
-typedef struct
-{
-    int encoded, valid, nf;
-    int32_t in_state[2], out_state[2], true_out[2];
-    int32_t (*used_const)[2];           /* [nf] frame-constant value handed to the kernel ... */
-    int32_t **used_arr;                 /* [nf] ... or the per-macroblock array (exact re-encode of a frame) */
-    h264e_hip_mbrec_t *rec;             /* [nf][nmb] */
-    uint8_t *rbsp; uint32_t rbsp_bytes;
-    uint32_t *off, *len;                /* [nf] */
-} gop_t;
-
-static void gop_free(gop_t *g)
-{
-    int f;
-    if (g->used_arr) for (f = 0; f < g->nf; f++) free(g->used_arr[f]);
-    free(g->used_const); free(g->used_arr); free(g->rec); free(g->rbsp); free(g->off); free(g->len);
-    memset(g, 0, sizeof(*g));
-}
-
-/* walk the GOP's records from `in`: returns 0 when every consumed rounded candidate equals what the kernel used */
-static int gop_check(const gop_t *g, int nmb, const int32_t in[2], int32_t out[2])
-{
-    int32_t c[2] = { in[0], in[1] };
-    int f, bad = 0;
-    for (f = 0; f < g->nf; f++)
-    {
-        const int per_mb = g->used_arr[f] != NULL;
-        if (clusters_walk(c, g->rec + (size_t)f*nmb, nmb, per_mb ? g->used_arr[f] : g->used_const[f], per_mb, NULL) >= 0) bad = 1;
-    }
-    out[0] = c[0]; out[1] = c[1];
-    return bad;
-}
-
 int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_bytes, int *frame_bytes, int profile, H264E_clip_stats_t *st)
 {
-    const int qp = c->par.qp, nmb = c->seq.nmb, G = c->gop_len, no_deblock = (c->par.speed == 8 || c->par.speed == 10);
+    const int qp = c->par.qp, nmb = c->seq.nmb, G = c->gop_len, K = c->ring, no_deblock = (c->par.speed == 8 || c->par.speed == 10);
     const int pic_init_qp = imax(imin(30, qp), qp);     /* qp_min = qp_max = qp (h264-lab.h:6768-6770) */
     const int idr_state = c->par.first_idr_pic_id_state & 1;
-    h264e_hip_task_t *tasks = (h264e_hip_task_t *)calloc((size_t)c->nchains, sizeof(*tasks));
-    h264e_hip_result_t *res = (h264e_hip_result_t *)calloc((size_t)G, sizeof(*res));
-    gop_t *gops = (gop_t *)calloc((size_t)c->ngops, sizeof(gop_t));
-    int *sel = (int *)calloc((size_t)c->nchains, sizeof(int)), *flags = (int *)calloc(2*(size_t)c->nchains, sizeof(int));
-    int32_t **arrs = (int32_t **)calloc((size_t)c->nchains, sizeof(int32_t *));
-    int32_t (*run)[2] = (int32_t (*)[2])calloc((size_t)c->nchains, sizeof(int32_t[2]));
-    const uint32_t arena_cap = (uint32_t)((size_t)G*((size_t)nmb*640 + 1024));
-    uint8_t *arena = (uint8_t *)malloc(arena_cap);
+    h264e_hip_task_t *tasks = (h264e_hip_task_t *)calloc((size_t)K, sizeof(*tasks));
+    int *flags = (int *)calloc(2*(size_t)K, sizeof(int));
+    int32_t (*used)[2] = (int32_t (*)[2])calloc((size_t)K, sizeof(int32_t[2]));
+    h264e_hip_mbrec_t *rec = (h264e_hip_mbrec_t *)malloc(sizeof(h264e_hip_mbrec_t)*(size_t)nmb);
+    int32_t *traj = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb), *first_arr = NULL;
+    const size_t rbsp_cap = (size_t)nmb*640 + 2048;
+    uint8_t *rbsp = (uint8_t *)malloc(rbsp_cap);
+    int32_t state[2] = { c->par.mv_clusters_in[0], c->par.mv_clusters_in[1] };
     uint16_t qdat_i[2][42], qdat_p[2][42];
     size_t pos = 0;
-    int rc = -1, f, k, g, first_open = 0;
+    int rc = -1, n = 0, i;
     H264E_clip_stats_t stats;
     double t0;
     memset(&stats, 0, sizeof(stats));
     g_host_err[0] = 0;
-    if (!tasks || !res || !gops || !sel || !flags || !run || !arena || !arrs) goto done;
+    if (!tasks || !flags || !used || !rec || !traj || !rbsp) goto done;
     build_qdat(qdat_i, qp, 0);
     build_qdat(qdat_p, qp, 1);
     h264e_hip_profile(c->pool, profile);
-    stats.chains = c->nchains;
-    for (g = 0; g < c->ngops; g++)
-    {
-        gops[g].nf = imin(G, c->nframes - g*G);
-        gops[g].in_state[0] = c->par.mv_clusters_in[0]; gops[g].in_state[1] = c->par.mv_clusters_in[1];   /* first guess: nothing moves */
-    }
+    stats.chains = K - 1;
 
-    while (first_open < c->ngops)
+    while (n < c->nframes)
     {
-        /* ---- pick the next GOPs that still need encoding, one per chain */
-        int ng = 0;
-        for (g = first_open; g < c->ngops && ng < c->nchains; g++)
-            if (!gops[g].encoded) sel[ng++] = g;
-        if (ng)
+        const int F = imin(K - 1, c->nframes - n);
+        int nvalid = 0;
+        t0 = now_ms();
+        memset(tasks, 0, sizeof(*tasks)*(size_t)K);
+        for (i = 0; i < F; i++)
         {
-            stats.rounds++;
-            t0 = now_ms();
-            for (k = 0; k < ng; k++)
+            h264e_hip_task_t *t = tasks + i;
+            const int f = n + i, key = (f % G) == 0;
+            t->active = 1; t->frame_index = f; t->frame_slot = 0;
+            t->slice_type = key ? SLICE_I : SLICE_P;
+            t->qp = qp; t->speed = c->par.speed;
+            /* frame_num restarts at every key frame; idr_pic_id toggles with every key frame (h264-lab.h:6774-6775) */
+            slice_header_bits(&c->seq, key, f % G, (idr_state ^ ((f/G + 1) & 1)), qp, pic_init_qp, no_deblock, &t->hdr_bits, &t->hdr_nbits);
+            memcpy(t->qdat, key ? qdat_i : qdat_p, sizeof(t->qdat));
+            t->stream_mode = 1; t->slot = f % K;
+            t->ref_slot = key ? -1 : (f - 1) % K;
+            t->ref_in_flight = !key && i > 0;
+            t->mv_clusters[0] = used[i][0] = state[0]; t->mv_clusters[1] = used[i][1] = state[1];
+            t->mv_clusters_per_mb = (i == 0) ? first_arr : NULL;
+        }
+        stats.rounds++;
+        if (h264e_hip_submit(c->pool, tasks) || h264e_hip_sync(c->pool) || h264e_hip_step_flags(c->pool, flags)) goto done;
+        stats.encode_ms += now_ms() - t0;
+
+        for (i = 0; i < F; i++)
+        {
+            const int f = n + i, key = (f % G) == 0, slot = f % K, per_mb = (i == 0 && first_arr != NULL);
+            int nb;
+            if (flags[2*i + 1]) { snprintf(g_host_err, sizeof(g_host_err), "bit buffer overflow (frame %d)", f); goto done; }
+            if (per_mb || flags[2*i] || used[i][0] != state[0] || used[i][1] != state[1])
             {
-                gop_t *q = gops + sel[k];
-                const int nf = q->nf;
-                int32_t keep[2] = { q->in_state[0], q->in_state[1] };
-                gop_free(q);
-                q->nf = nf; q->in_state[0] = keep[0]; q->in_state[1] = keep[1];
-                q->used_const = (int32_t (*)[2])calloc((size_t)nf, sizeof(int32_t[2]));
-                q->used_arr = (int32_t **)calloc((size_t)nf, sizeof(int32_t *));
-                q->off = (uint32_t *)calloc((size_t)nf, sizeof(uint32_t));
-                q->len = (uint32_t *)calloc((size_t)nf, sizeof(uint32_t));
-                if (!q->used_const || !q->used_arr || !q->off || !q->len) goto done;
-                run[k][0] = keep[0]; run[k][1] = keep[1];
-                if (h264e_hip_reset_results(c->pool, k)) goto done;
-            }
-            for (f = 0; f < G; f++)
-            {
-                int any = 0;
-                memset(tasks, 0, sizeof(*tasks)*(size_t)c->nchains);
-                for (k = 0; k < ng; k++)
+                /* exact walk: does every consumed (rounded) candidate equal what the kernel was given? */
+                int32_t cc[2] = { state[0], state[1] };
+                int bad;
+                t0 = now_ms();
+                if (h264e_hip_read_mbrec(c->pool, slot, 0, rec)) goto done;
+                stats.readback_ms += now_ms() - t0;
+                bad = clusters_walk(cc, rec, nmb, per_mb ? first_arr : used[i], per_mb, traj) >= 0;
+                if (bad)
                 {
-                    h264e_hip_task_t *t = tasks + k;
-                    gop_t *q = gops + sel[k];
-                    if (f >= q->nf) continue;
-                    any = 1;
-                    t->active = 1; t->frame_index = sel[k]*G + f; t->frame_slot = f;
-                    t->slice_type = f ? SLICE_P : SLICE_I;
-                    t->qp = qp; t->speed = c->par.speed;
-                    /* idr_pic_id toggles with every key frame (h264-lab.h:6774) */
-                    slice_header_bits(&c->seq, !f, f, (idr_state ^ ((sel[k] + 1) & 1)), qp, pic_init_qp, no_deblock, &t->hdr_bits, &t->hdr_nbits);
-                    t->mv_clusters[0] = run[k][0]; t->mv_clusters[1] = run[k][1];
-                    q->used_const[f][0] = run[k][0]; q->used_const[f][1] = run[k][1];
-                    memcpy(t->qdat, f ? qdat_p : qdat_i, sizeof(t->qdat));
+                    /* frames from here on are void: relaunch with exact per-macroblock values for this one */
+                    if (!first_arr) first_arr = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb);
+                    if (!first_arr) goto done;
+                    memcpy(first_arr, traj, sizeof(int32_t)*2*(size_t)nmb);
+                    stats.reencoded_gops++;             /* counts relaunches */
+                    break;
                 }
-                if (!any) break;
-                {
-                    int extra = 0;
-                    memset(arrs, 0, sizeof(int32_t *)*(size_t)c->nchains);
-                    if (step_exact(c->pool, c->nchains, tasks, nmb, run, arrs, &extra)) goto done;
-                    stats.reencoded_gops += extra;          /* counts extra launches (exact passes) + re-encoded GOPs */
-                    for (k = 0; k < ng; k++)
-                        if (f < gops[sel[k]].nf) gops[sel[k]].used_arr[f] = arrs[k]; else free(arrs[k]);
-                }
+                state[0] = cc[0]; state[1] = cc[1];
             }
-            stats.encode_ms += now_ms() - t0;
+            if (i == 0 && first_arr) { free(first_arr); first_arr = NULL; }
             t0 = now_ms();
-            for (k = 0; k < ng; k++)
-            {
-                gop_t *q = gops + sel[k];
-                uint32_t used = 0;
-                if (h264e_hip_read_chain(c->pool, k, q->nf, res, q->off, arena, arena_cap, &used)) goto done;
-                q->rbsp = (uint8_t *)malloc(used ? used : 1);
-                q->rec = (h264e_hip_mbrec_t *)malloc(sizeof(h264e_hip_mbrec_t)*(size_t)nmb*(size_t)q->nf);
-                if (!q->rbsp || !q->rec) goto done;
-                memcpy(q->rbsp, arena, used);
-                q->rbsp_bytes = used;
-                for (f = 0; f < q->nf; f++) q->len[f] = res[f].nbytes;
-                if (h264e_hip_read_mbrec_all(c->pool, k, q->nf, q->rec)) goto done;
-                q->out_state[0] = run[k][0]; q->out_state[1] = run[k][1];
-                q->encoded = 1;
-            }
+            nb = h264e_hip_read_rbsp(c->pool, slot, 0, rbsp, (uint32_t)rbsp_cap);
+            if (nb < 0) goto done;
             stats.readback_ms += now_ms() - t0;
-        }
-
-        /* ---- validate in stream order; predict better input states for what has to be redone */
-        {
-            int32_t state[2], exact = 1;
-            if (first_open == 0) { state[0] = c->par.mv_clusters_in[0]; state[1] = c->par.mv_clusters_in[1]; }
-            else { state[0] = gops[first_open - 1].true_out[0]; state[1] = gops[first_open - 1].true_out[1]; }
-            for (g = first_open; g < c->ngops; g++)
+            t0 = now_ms();
             {
-                gop_t *q = gops + g;
-                int32_t o[2];
-                if (!q->encoded)
-                {
-                    /* not encoded yet: start it from the best prediction we have */
-                    q->in_state[0] = state[0]; q->in_state[1] = state[1];
-                    exact = 0;
-                    continue;
-                }
-                if (gop_check(q, nmb, state, o))
-                {
-                    q->encoded = 0;                 /* consumed candidates differ: encode again from `state` */
-                    q->in_state[0] = state[0]; q->in_state[1] = state[1];
-                    if (exact) stats.reencoded_gops++;
-                    exact = 0;
-                    /* keep walking with the stale records: still the best prediction for the GOPs behind it */
-                } else if (exact)
-                {
-                    q->valid = 1;
-                    q->true_out[0] = o[0]; q->true_out[1] = o[1];
-                    first_open = g + 1;
-                }
-                state[0] = o[0]; state[1] = o[1];
+                size_t start = pos, need = nal_escaped_size(rbsp, (size_t)nb) + (key ? 64 : 0);
+                if (pos + need > cap) { snprintf(g_host_err, sizeof(g_host_err), "output buffer too small"); goto done; }
+                if (key) pos += write_sps_pps(&c->seq, pic_init_qp, out + pos);
+                pos += nal_emit(out + pos, rbsp, (size_t)nb);
+                if (frame_bytes) frame_bytes[f] = (int)(pos - start);
             }
-            if (getenv("H264E_DEBUG")) fprintf(stderr, "clip round %d: encoded %d GOPs, valid prefix %d/%d\n", stats.rounds, ng, first_open, c->ngops);
+            stats.assemble_ms += now_ms() - t0;
+            nvalid++;
         }
+        n += nvalid;
+        if (getenv("H264E_DEBUG")) fprintf(stderr, "clip launch %d: %d frames in flight, %d valid, next %d\n", stats.rounds, F, nvalid, n);
     }
-
-    t0 = now_ms();
-    for (g = 0; g < c->ngops; g++)
-    {
-        gop_t *q = gops + g;
-        for (f = 0; f < q->nf; f++)
-        {
-            const uint8_t *rb = q->rbsp + q->off[f];
-            size_t start = pos, need = nal_escaped_size(rb, q->len[f]) + (f ? 0 : 64);
-            if (pos + need > cap) { snprintf(g_host_err, sizeof(g_host_err), "output buffer too small"); goto done; }
-            if (!f) pos += write_sps_pps(&c->seq, pic_init_qp, out + pos);
-            pos += nal_emit(out + pos, rb, q->len[f]);
-            if (frame_bytes) frame_bytes[g*G + f] = (int)(pos - start);
-        }
-    }
-    stats.assemble_ms += now_ms() - t0;
-    stats.mv_clusters_out[0] = gops[c->ngops - 1].true_out[0]; stats.mv_clusters_out[1] = gops[c->ngops - 1].true_out[1];
-    stats.next_idr_pic_id_state = idr_state ^ (c->ngops & 1);
+    stats.mv_clusters_out[0] = state[0]; stats.mv_clusters_out[1] = state[1];
+    stats.next_idr_pic_id_state = idr_state ^ (((c->nframes + G - 1)/G) & 1);
     h264e_hip_profile_read(c->pool, &stats.mb_kernel_ms, &stats.splice_kernel_ms, &stats.kernel_launches);
     if (out_bytes) *out_bytes = pos;
     rc = 0;
 done:
     if (st) *st = stats;
-    if (gops) for (g = 0; g < c->ngops; g++) gop_free(gops + g);
-    free(tasks); free(res); free(gops); free(sel); free(flags); free(run); free(arena); free(arrs);
+    free(tasks); free(flags); free(used); free(rec); free(traj); free(rbsp); free(first_arr);
     return rc;
 }

@@ -31,48 +31,57 @@ extern "C" const char *h264e_hip_last_error(void) { return g_err; }
 
 #ifndef H264E_EMU
 
-#define SPIN_LIMIT (1u << 22)
+#define SPIN_LIMIT (1u << 24)
+
+/* relaxed poll of one progress counter until it reaches `need`; false when the producer gave up or the bound expired */
+DEV bool poll_progress(const int *flag, int need, int &seen)
+{
+    unsigned spins = 0;
+    for (;;)
+    {
+        seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen >= need) return true;
+        if (++spins > SPIN_LIMIT || seen < 0) return false;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
 
 __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h264e_chain_dev_t *chains,
-                                                      const h264e_frame_task_t *tasks, int nchains, int *errflag)
+                                                         const h264e_frame_task_t *tasks, int njobs, int *errflag)
 {
     __shared__ RowLds L;
-    const int chain = (int)(blockIdx.x % (unsigned)nchains), row = (int)(blockIdx.x / (unsigned)nchains);
-    const h264e_frame_task_t &T = tasks[chain];
+    /* job-major: every workgroup a job waits for (row above; rows of the reference frame's job) has a lower index */
+    const int job = (int)(blockIdx.x / (unsigned)G.nmby), row = (int)(blockIdx.x % (unsigned)G.nmby);
+    (void)njobs;
+    const h264e_frame_task_t &T = tasks[job];
     if (!T.active) return;
-    const h264e_chain_dev_t &C = chains[chain];
+    const h264e_chain_dev_t &C = chains[T.chain];
     row_begin(L, G, C, T, row);
-    int seen = 0;
+    int seen = 0, seen_dep = 0;
+    const int dep_row = imin(row + 3, G.nmby - 1);
     for (int x = 0; x < G.nmbx; x++)
     {
-        if (row > 0)
+        /* consumer: relaxed polls, then ONE agent-scope acquire (invalidates this CU's L1) */
+        const int need = row > 0 ? imin(x + 2, G.nmbx) : 0;
+        const int need_dep = T.dep_progress ? imin(x + 4, G.nmbx) : 0;     /* temporal wavefront: see rv_wait_rect */
+        if (seen < need || seen_dep < need_dep)
         {
-            const int need = imin(x + 2, G.nmbx);
-            if (seen < need)
+            bool ok = true;
+            if (seen < need) ok = poll_progress(C.progress + (row - 1), need, seen);
+            if (ok && seen_dep < need_dep) ok = poll_progress(T.dep_progress + dep_row, need_dep, seen_dep);
+            if (!ok)
             {
-                /* consumer: ONE relaxed poll loop, then ONE agent-scope acquire (invalidates this CU's L1) */
-                unsigned spins = 0;
-                int *flag = C.progress + (row - 1);
-                for (;;)
+                /* bounded spin: give up, poison this row's counter so everything behind it stops too */
+                if (threadIdx.x == 0)
                 {
-                    seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (seen >= need) break;
-                    if (++spins > SPIN_LIMIT || seen < 0)
-                    {
-                        /* bounded spin: give up, poison this row's counter so the rows below stop too */
-                        if (threadIdx.x == 0)
-                        {
-                            *errflag = 1;
-                            __hip_atomic_store(C.progress + row, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        return;
-                    }
-                    __builtin_amdgcn_s_sleep(8);
+                    *errflag = 1;
+                    __hip_atomic_store(C.progress + row, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                return;
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
         STAMP(L, 13);
         row_step(L, G, C, T, row, x);
@@ -95,7 +104,7 @@ __global__ void __launch_bounds__(64) h264e_splice_kernel(h264e_geom_t G, const 
 {
     const h264e_frame_task_t &T = tasks[blockIdx.x];
     if (!T.active) return;
-    finalize_frame(G, chains[blockIdx.x], T, stepflags + 2*blockIdx.x);
+    finalize_frame(G, chains[T.chain], T, stepflags + 2*blockIdx.x);
 }
 
 #endif
@@ -408,7 +417,31 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         d.in_stride[0] = G.width; d.in_stride[1] = d.in_stride[2] = G.width/2;
         d.slice_type = t.slice_type; d.qp = t.qp; d.speed = t.speed;
         d.no_deblock = (t.speed == 8 || t.speed == 10);                 /* h264-lab.h:6717 */
-        d.ref_sel = p->ref_sel[c];
+        if (t.stream_mode)
+        {
+            /* temporal wavefront: job c builds the picture of chain slot t.slot from the picture of slot t.ref_slot */
+            if (t.slot < 0 || t.slot >= p->nchains || t.ref_slot >= p->nchains || (t.slice_type == 0 && t.ref_slot < 0) ||
+                (t.ref_in_flight && t.ref_slot < 0))
+            {
+                free(host);
+                FAIL("submit: bad stream task %d", c);
+            }
+            d.chain = t.slot;
+            d.arena_reset = 1;
+            for (int k = 0; k < 3; k++)
+            {
+                d.dec[k] = p->chains_host[t.slot].rec[0][k];
+                d.ref[k] = t.ref_slot >= 0 ? p->chains_host[t.ref_slot].rec[0][k] : p->chains_host[t.slot].rec[1][k];
+            }
+            d.dep_progress = t.ref_in_flight ? p->chains_host[t.ref_slot].progress : 0;
+        } else
+        {
+            const int rs = p->ref_sel[c];
+            d.chain = c;
+            for (int k = 0; k < 3; k++) { d.ref[k] = p->chains_host[c].rec[rs][k]; d.dec[k] = p->chains_host[c].rec[rs ^ 1][k]; }
+            d.dep_progress = 0;
+            p->ref_sel[c] ^= 1;
+        }
         d.frame_slot = t.frame_slot;
         d.hdr_nbits = t.hdr_nbits; d.hdr_bits = t.hdr_bits;
         d.clusters[0] = t.mv_clusters[0]; d.clusters[1] = t.mv_clusters[1];
@@ -416,21 +449,21 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         if (t.mv_clusters_per_mb)
         {
             const size_t n = sizeof(int32_t)*2*(size_t)G.nmb;
-            if (!p->clu_dev[c] && dev_malloc((void **)&p->clu_dev[c], n)) { free(host); FAIL("device allocation failed"); }
+            const int cs = t.stream_mode ? t.slot : c;
+            if (!p->clu_dev[cs] && dev_malloc((void **)&p->clu_dev[cs], n)) { free(host); FAIL("device allocation failed"); }
 #ifdef H264E_EMU
-            memcpy(p->clu_dev[c], t.mv_clusters_per_mb, n);
+            memcpy(p->clu_dev[cs], t.mv_clusters_per_mb, n);
 #else
             /* the re-encode path is rare and synchronous: a blocking copy keeps the host array's lifetime simple */
-            if (hipStreamSynchronize(p->stream) != hipSuccess || hipMemcpy(p->clu_dev[c], t.mv_clusters_per_mb, n, hipMemcpyHostToDevice) != hipSuccess)
+            if (hipStreamSynchronize(p->stream) != hipSuccess || hipMemcpy(p->clu_dev[cs], t.mv_clusters_per_mb, n, hipMemcpyHostToDevice) != hipSuccess)
             {
                 free(host);
                 FAIL("mv_clusters upload failed");
             }
 #endif
-            d.clusters_per_mb = p->clu_dev[c];
+            d.clusters_per_mb = p->clu_dev[cs];
         }
         memcpy(d.qdat, t.qdat, sizeof(d.qdat));
-        p->ref_sel[c] ^= 1;
     }
     if (!any) { free(host); return 0; }
     h264e_frame_task_t *slot = p->tasks_dev + (size_t)p->ring_pos*p->nchains;
@@ -443,7 +476,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     {
         const h264e_frame_task_t &T = slot[c];
         if (!T.active) continue;
-        const h264e_chain_dev_t &C = p->chains_dev[c];
+        const h264e_chain_dev_t &C = p->chains_dev[T.chain];
         for (int row = 0; row < G.nmby; row++)
         {
             RowLds *L = (RowLds *)calloc(1, sizeof(RowLds));

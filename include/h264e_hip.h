@@ -36,6 +36,10 @@ typedef struct
     int32_t mv_clusters[2];     /* speculated enc->mv_clusters for the whole frame (h264-lab.h:766) */
     const int32_t *mv_clusters_per_mb;  /* optional HOST array [nmb][2]: exact per-macroblock values (re-encode path) */
     uint16_t qdat[2][42];       /* quantizer tables of rc_set_qp (h264-lab.h:5839-5912) */
+    /* temporal wavefront (stream_mode = 1): the tasks of one submit are consecutive frames of ONE stream, in order;
+     * task i builds the picture of chain slot `slot` and references the picture of `ref_slot` (-1: none, I slice),
+     * which is either complete or (ref_in_flight) being built by an earlier task of this same submit, a few rows ahead */
+    int stream_mode, slot, ref_slot, ref_in_flight;
 } h264e_hip_task_t;
 
 typedef struct
