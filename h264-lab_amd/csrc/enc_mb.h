@@ -186,6 +186,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
     mv32 v;
     mv = (mv32)uni(mv); mv_pred = (mv32)uni(mv_pred); min_sad = uni(min_sad);
     const int g = w >> 2, n = g*h;
+    PCOUNT(L, 18);
     for (;;)
     {
         dir = 0; cloop = 4; dir_prev = -1;
@@ -196,10 +197,13 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
         do
         {
             v = mvadd(mv, mvmk(DX(dir), DY(dir)));
+            PCOUNT(L, 19);
             if (in_rect(v, range) && CGET(cur, dir) == 0xffffu)
             {
                 if (!(have & (1 << dir)))
                 {
+                    PCOUNT(L, 17);
+                    PTIC();
                     int want = 0, s4[4];
 #pragma unroll
                     for (int d = 0; d < 4; d++)
@@ -236,6 +240,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
                     }
                     bs0 = s4[0]; bs1 = s4[1]; bs2 = s4[2]; bs3 = s4[3];
                     have = want;
+                    PTOC(L, 16);
                 }
                 cost = (dir == 0 ? bs0 : dir == 1 ? bs1 : dir == 2 ? bs2 : bs3) + mv_cost(m, v, mv_pred);
                 CSET(cur, dir, (uint32_t)cost);
@@ -261,7 +266,9 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
         v = mvadd(mv, mvmk(DX(pri) + DX(sec), DY(pri) + DY(sec)));
         if (in_rect(v, range))
         {
+            PTIC();
             cost = wave_sad_ref(R, px + (mvx(v) >> 2), py + (mvy(v) >> 2), b, w, h) + mv_cost(m, v, mv_pred);
+            PTOC(L, 23);
             if (cost < min_sad)
             {
                 mv = v;
@@ -490,7 +497,7 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
     {
         int imv = 0, part_sad = MUL_LAMBDA(t == 0 ? 1 : t == 3 ? 12 : 4, m.lambda_q4);
         const int w = (t & 2) ? 8 : 16, h = (t & 1) ? 8 : 16;
-        int px = 0, py = 0;
+        int px = 0, py = 0, lost = 0;
         if (!(t == 0 ? prefer[0] : t == 1 ? prefer[1] : t == 2 ? prefer[2] : prefer[3])) continue;
         for (;;)
         {
@@ -506,6 +513,9 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
                          + mv_cost(m, mvabs, mb_abs(m, mvp));
             }
             part_sad += diamond(L, m, px, py, mvabs, range, mb_abs(m, mvp), sad_best, w, h);
+            /* the partition costs only add up: once they reach the best cost so far this partitioning cannot win (H:5500 is a
+             * strict "<"), and nothing else of it is observable -- the predictor context is restored below */
+            if (part_sad >= m.cost) { lost = 1; break; }
             wave_copy_wh(L.test + 16*py + px, L.blk, w, h);
             const mv32 mv = mvsub(mvabs, mvmk(m.x*64, m.y*64));
             L.part_mvd[t][imv] = mvsub(mv, mvp);
@@ -521,7 +531,7 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
         }
         for (int i = 0; i < 4; i++) { L.mv_left[i] = L.ctx_save[i]; L.mv_tl[i] = L.ctx_save[4 + i]; L.mv_top[i] = L.ctx_save[8 + i]; }
         wave_sync();
-        if (part_sad < m.cost)
+        if (!lost && part_sad < m.cost)
         {
             wave_copy_wh(L.pred, L.test, 16, 16);
             m.cost = part_sad;

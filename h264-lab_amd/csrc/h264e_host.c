@@ -725,6 +725,7 @@ int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nfram
     nmby = (par->height + 15) >> 4;
     cap = imax(2, 1800/nmby);
     c->ring = par->max_chains > 0 ? par->max_chains + 1 : 17;
+    if (getenv("H264E_RING")) c->ring = atoi(getenv("H264E_RING"));       /* experiments */
     c->ring = imin(imin(c->ring, cap + 1), nframes + 1);
     if (h264e_hip_pool_create(&c->pool, par->device, par->width, par->height, c->ring, nframes, 1))
     {

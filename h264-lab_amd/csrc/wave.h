@@ -141,8 +141,14 @@ DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 /* diagnostic build only (-DH264E_STAMPS): cycle stamps per pipeline phase, accumulated in LDS (never in the product) */
 #if defined(H264E_STAMPS) && !defined(H264E_EMU)
 #define STAMP(L, id) do { unsigned long long t_ = __builtin_readcyclecounter(); (L).prof[id] += t_ - (L).prof_last; (L).prof_last = t_; } while (0)
+#define PCOUNT(L, id) do { (L).prof[id]++; } while (0)
+#define PTIC() unsigned long long tic_ = __builtin_readcyclecounter()
+#define PTOC(L, id) do { (L).prof[id] += __builtin_readcyclecounter() - tic_; } while (0)
 #else
 #define STAMP(L, id) do { } while (0)
+#define PCOUNT(L, id) do { } while (0)
+#define PTIC() do { } while (0)
+#define PTOC(L, id) do { } while (0)
 #endif
 
 typedef LDS_AS uint8_t lu8;                           /* a byte in LDS (explicit, so out-of-line functions keep ds_* instructions) */

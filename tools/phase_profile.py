@@ -36,6 +36,9 @@ def main():
     for i in range(15):
         print("%-42s %12.0f %7.1f%% %10.2f" % (NAMES[i], t[i] / nmb, 100.0 * t[i] / tot, t[i] / nmb / 2100.0))
     print("%-42s %12.0f %8s %10.2f" % ("total", tot / nmb, "", tot / nmb / 2100.0))
+    if t[18]:
+        print("diamond calls/MB %.2f  scan iterations/call %.1f  SAD batches/call %.2f  cycles/batch %.0f  cycles/diag-probe-phase per call %.0f" %
+              (t[18] / nmb, t[19] / t[18], t[17] / t[18], t[16] / max(t[17], 1), t[23] / t[18]))
 
 
 if __name__ == "__main__":
