@@ -67,6 +67,15 @@ typedef struct
     int32_t pad[3];
 } h264e_frameout_t;
 
+/* per-job result record in HOST (pinned, device-mapped) memory: lets the host consume frames while the launch runs */
+typedef struct
+{
+    uint32_t nbytes;
+    int32_t all_skipped, clusters_moved, overflow;
+    int32_t pad[3];
+    int32_t done;                       /* written last: launch id when the job's results are complete, -launch id when it was aborted */
+} h264e_hostdone_t;
+
 typedef struct
 {
     uint8_t *rec[2][3];
@@ -102,6 +111,12 @@ typedef struct
     mv32 clusters[2];                   /* speculated mv_clusters state for every macroblock of the frame ... */
     const mv32 *clusters_per_mb;        /* ... or, when not NULL, an exact per-macroblock trajectory [nmb][2] */
     uint16_t qdat[2][42];               /* quantizer tables (h264-lab.h:5839-5912), built by the host */
+    int launch_id;                      /* > 0, unique per submit */
+    const int *abort_word;              /* host-mapped, or NULL: the job stops once *abort_word == launch_id */
+    h264e_hostdone_t *host_done;        /* host-mapped result record, or NULL */
+    uint8_t *host_rbsp;                 /* host-mapped copy of the RBSP (capacity host_rbsp_cap), or NULL */
+    uint32_t host_rbsp_cap;
+    h264e_mbrec_t *host_mbrec;          /* host-mapped copy of the macroblock records [nmb], or NULL */
 } h264e_frame_task_t;
 
 #endif

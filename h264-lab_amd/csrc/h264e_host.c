@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <sched.h>
 #include "../../include/h264e_mi355x.h"
 #include "../../include/h264e_hip.h"
 
@@ -721,12 +722,12 @@ int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nfram
     seq_init(&c->seq, par->width, par->height, par->vbv_size_bytes, 0);
     c->nframes = nframes;
     c->gop_len = par->gop ? par->gop : nframes;
-    /* frames in flight + 1: bounded by what the GPU keeps resident (2 waves/SIMD x 1024 SIMDs, one wave per macroblock row) */
-    nmby = (par->height + 15) >> 4;
-    cap = imax(2, 1800/nmby);
-    c->ring = par->max_chains > 0 ? par->max_chains + 1 : 17;
+    /* ring of picture / result slots = frames per launch + 1.  Not bounded by residency: workgroups only wait for lower
+     * block indices, so a launch larger than the GPU simply streams through it in order. */
+    (void)nmby; (void)cap;
+    c->ring = par->max_chains > 0 ? par->max_chains + 1 : 49;
     if (getenv("H264E_RING")) c->ring = atoi(getenv("H264E_RING"));       /* experiments */
-    c->ring = imin(imin(c->ring, cap + 1), nframes + 1);
+    c->ring = imax(2, imin(c->ring, nframes + 1));
     if (h264e_hip_pool_create(&c->pool, par->device, par->width, par->height, c->ring, nframes, 1))
     {
         free(c);
@@ -771,8 +772,10 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
     h264e_hip_mbrec_t *rec = (h264e_hip_mbrec_t *)malloc(sizeof(h264e_hip_mbrec_t)*(size_t)nmb);
     int32_t *traj = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb), *first_arr = NULL;
     const size_t rbsp_cap = (size_t)nmb*640 + 2048;
-    uint8_t *rbsp = (uint8_t *)malloc(rbsp_cap);
+    uint8_t *rbsp = (uint8_t *)malloc(rbsp_cap);      /* unused by the streaming path, kept for the size check */
     int32_t state[2] = { c->par.mv_clusters_in[0], c->par.mv_clusters_in[1] };
+    int32_t after[2] = { 0, 0 };            /* after a failed validation: predicted state behind the frame that is encoded again */
+    int have_after = 0;
     uint16_t qdat_i[2][42], qdat_p[2][42];
     size_t pos = 0;
     int rc = -1, n = 0, i;
@@ -805,33 +808,48 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             t->stream_mode = 1; t->slot = f % K;
             t->ref_slot = key ? -1 : (f - 1) % K;
             t->ref_in_flight = !key && i > 0;
-            t->mv_clusters[0] = used[i][0] = state[0]; t->mv_clusters[1] = used[i][1] = state[1];
+            /* frame 0 of the launch gets the exact state; the frames behind it the best prediction of what it leaves */
+            t->mv_clusters[0] = used[i][0] = (i && have_after) ? after[0] : state[0];
+            t->mv_clusters[1] = used[i][1] = (i && have_after) ? after[1] : state[1];
             t->mv_clusters_per_mb = (i == 0) ? first_arr : NULL;
         }
         stats.rounds++;
-        if (h264e_hip_submit(c->pool, tasks) || h264e_hip_sync(c->pool) || h264e_hip_step_flags(c->pool, flags)) goto done;
-        stats.encode_ms += now_ms() - t0;
+        have_after = 0;
+        if (h264e_hip_submit(c->pool, tasks)) goto done;
 
+        /* consume the frames in stream order while the launch is still running */
         for (i = 0; i < F; i++)
         {
             const int f = n + i, key = (f % G) == 0, slot = f % K, per_mb = (i == 0 && first_arr != NULL);
-            int nb;
-            if (flags[2*i + 1]) { snprintf(g_host_err, sizeof(g_host_err), "bit buffer overflow (frame %d)", f); goto done; }
-            if (per_mb || flags[2*i] || used[i][0] != state[0] || used[i][1] != state[1])
+            h264e_hip_result_t r1;
+            int dn, idle = 0;
+            while ((dn = h264e_hip_stream_done(c->pool, slot, &r1)) == 0)
+            {
+                if (!h264e_hip_busy(c->pool) && ++idle > 2) break;      /* the launch ended without finishing this job */
+                sched_yield();
+            }
+            if (dn == 0) dn = h264e_hip_stream_done(c->pool, slot, &r1);
+            if (dn != 1)
+            {
+                if (dn < 0) goto done;
+                (void)h264e_hip_sync(c->pool);                          /* reports a kernel-side failure, if any */
+                if (!g_host_err[0] && !h264e_hip_last_error()[0]) snprintf(g_host_err, sizeof(g_host_err), "frame %d did not complete", f);
+                goto done;
+            }
+            if (r1.overflow) { snprintf(g_host_err, sizeof(g_host_err), "bit buffer overflow (frame %d)", f); (void)h264e_hip_stream_abort(c->pool); (void)h264e_hip_sync(c->pool); goto done; }
+            if (per_mb || r1.clusters_moved || used[i][0] != state[0] || used[i][1] != state[1])
             {
                 /* exact walk: does every consumed (rounded) candidate equal what the kernel was given? */
                 int32_t cc[2] = { state[0], state[1] };
-                int bad;
-                t0 = now_ms();
-                if (h264e_hip_read_mbrec(c->pool, slot, 0, rec)) goto done;
-                stats.readback_ms += now_ms() - t0;
-                bad = clusters_walk(cc, rec, nmb, per_mb ? first_arr : used[i], per_mb, traj) >= 0;
+                const int bad = clusters_walk(cc, h264e_hip_stream_mbrec(c->pool, slot), nmb, per_mb ? first_arr : used[i], per_mb, traj) >= 0;
                 if (bad)
                 {
-                    /* frames from here on are void: relaunch with exact per-macroblock values for this one */
+                    /* frames from here on are void: stop the launch, go again with exact per-macroblock values for this one */
+                    if (h264e_hip_stream_abort(c->pool)) goto done;
                     if (!first_arr) first_arr = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb);
                     if (!first_arr) goto done;
                     memcpy(first_arr, traj, sizeof(int32_t)*2*(size_t)nmb);
+                    after[0] = cc[0]; after[1] = cc[1]; have_after = 1;     /* the walk's end: what this frame most likely leaves behind */
                     stats.reencoded_gops++;             /* counts relaunches */
                     break;
                 }
@@ -839,20 +857,19 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             }
             if (i == 0 && first_arr) { free(first_arr); first_arr = NULL; }
             t0 = now_ms();
-            nb = h264e_hip_read_rbsp(c->pool, slot, 0, rbsp, (uint32_t)rbsp_cap);
-            if (nb < 0) goto done;
-            stats.readback_ms += now_ms() - t0;
-            t0 = now_ms();
             {
-                size_t start = pos, need = nal_escaped_size(rbsp, (size_t)nb) + (key ? 64 : 0);
-                if (pos + need > cap) { snprintf(g_host_err, sizeof(g_host_err), "output buffer too small"); goto done; }
+                const uint8_t *rb = h264e_hip_stream_rbsp(c->pool, slot);
+                size_t start = pos, need = nal_escaped_size(rb, r1.nbytes) + (key ? 64 : 0);
+                if (pos + need > cap) { snprintf(g_host_err, sizeof(g_host_err), "output buffer too small"); (void)h264e_hip_stream_abort(c->pool); (void)h264e_hip_sync(c->pool); goto done; }
                 if (key) pos += write_sps_pps(&c->seq, pic_init_qp, out + pos);
-                pos += nal_emit(out + pos, rbsp, (size_t)nb);
+                pos += nal_emit(out + pos, rb, r1.nbytes);
                 if (frame_bytes) frame_bytes[f] = (int)(pos - start);
             }
             stats.assemble_ms += now_ms() - t0;
             nvalid++;
         }
+        if (h264e_hip_sync(c->pool)) goto done;         /* the launch has drained (immediately after an abort) */
+        stats.encode_ms += now_ms() - t0;
         n += nvalid;
         if (getenv("H264E_DEBUG")) fprintf(stderr, "clip launch %d: %d frames in flight, %d valid, next %d\n", stats.rounds, F, nvalid, n);
     }

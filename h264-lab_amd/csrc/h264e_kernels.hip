@@ -33,29 +33,79 @@ extern "C" const char *h264e_hip_last_error(void) { return g_err; }
 
 #define SPIN_LIMIT (1u << 24)
 
-/* relaxed poll of one progress counter until it reaches `need`; false when the producer gave up or the bound expired */
-DEV bool poll_progress(const int *flag, int need, int &seen)
+/* relaxed poll of one progress counter until it reaches `need`.  Returns 0 = reached, -1 = producer failed or the
+ * bound expired, -2 = producer was aborted (negative counters are poison left behind by a row that stopped). */
+DEV int poll_progress(const int *flag, int need, int &seen)
 {
     unsigned spins = 0;
     for (;;)
     {
         seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen >= need) return true;
-        if (++spins > SPIN_LIMIT || seen < 0) return false;
+        if (seen >= need) return 0;
+        if (seen < 0) return seen;
+        if (++spins > SPIN_LIMIT) return -1;
         __builtin_amdgcn_s_sleep(8);
     }
 }
 
+/*
+ * Grid: njobs x (nmby + 1) workgroups of one wavefront, job-major.  Workgroup `row < nmby` encodes macroblock row
+ * `row` of its job's frame; workgroup `nmby` is the job's finalizer: once every row has ended it splices the slice
+ * (finalize_frame) and, in streaming use, exports the result to host-mapped memory and raises the job's done word,
+ * so the host consumes frames while later frames of the same launch are still being encoded.
+ * Every workgroup only ever waits for workgroups with a lower index (rows above; rows of the reference frame's job;
+ * rows of the own job for the finalizer).
+ */
 __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h264e_chain_dev_t *chains,
-                                                         const h264e_frame_task_t *tasks, int njobs, int *errflag)
+                                                         const h264e_frame_task_t *tasks, int njobs, int *errflag, int *stepflags)
 {
     __shared__ RowLds L;
-    /* job-major: every workgroup a job waits for (row above; rows of the reference frame's job) has a lower index */
-    const int job = (int)(blockIdx.x / (unsigned)G.nmby), row = (int)(blockIdx.x % (unsigned)G.nmby);
+    const int job = (int)(blockIdx.x / (unsigned)(G.nmby + 1)), row = (int)(blockIdx.x % (unsigned)(G.nmby + 1));
     (void)njobs;
     const h264e_frame_task_t &T = tasks[job];
     if (!T.active) return;
     const h264e_chain_dev_t &C = chains[T.chain];
+
+    if (row == G.nmby)
+    {
+        /* ---- finalizer */
+        int st = 0, seen = 0;
+        for (int r = G.nmby - 1; r >= 0 && !st; r--) st = poll_progress(C.progress + r, G.nmbx + 1, seen);
+        if (st)
+        {
+            if (threadIdx.x == 0)
+            {
+                if (st == -1) *errflag = 1;
+                if (T.host_done) __hip_atomic_store(&T.host_done->done, -T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        finalize_frame(G, C, T, stepflags + 2*job);
+        if (T.host_done)
+        {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            export_frame(G, C, T);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0)
+            {
+                const h264e_frameout_t &F = C.fout[T.frame_slot];
+                T.host_done->nbytes = F.nbytes; T.host_done->all_skipped = F.all_skipped;
+                T.host_done->clusters_moved = F.clusters_moved; T.host_done->overflow = F.overflow;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                 /* system scope: the host reads these */
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&T.host_done->done, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
+
+    /* ---- macroblock row */
     row_begin(L, G, C, T, row);
     int seen = 0, seen_dep = 0;
     const int dep_row = imin(row + 3, G.nmby - 1);
@@ -64,24 +114,28 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
         /* consumer: relaxed polls, then ONE agent-scope acquire (invalidates this CU's L1) */
         const int need = row > 0 ? imin(x + 2, G.nmbx) : 0;
         const int need_dep = T.dep_progress ? imin(x + 4, G.nmbx) : 0;     /* temporal wavefront: see rv_wait_rect */
-        if (seen < need || seen_dep < need_dep)
+        int st = 0;
+        if (T.abort_word && __hip_atomic_load(T.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == T.launch_id) st = -2;
+        if (!st && (seen < need || seen_dep < need_dep))
         {
-            bool ok = true;
-            if (seen < need) ok = poll_progress(C.progress + (row - 1), need, seen);
-            if (ok && seen_dep < need_dep) ok = poll_progress(T.dep_progress + dep_row, need_dep, seen_dep);
-            if (!ok)
+            if (seen < need) st = poll_progress(C.progress + (row - 1), need, seen);
+            if (!st && seen_dep < need_dep) st = poll_progress(T.dep_progress + dep_row, need_dep, seen_dep);
+            if (!st)
             {
-                /* bounded spin: give up, poison this row's counter so everything behind it stops too */
-                if (threadIdx.x == 0)
-                {
-                    *errflag = 1;
-                    __hip_atomic_store(C.progress + row, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                return;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+        }
+        if (st)
+        {
+            /* stop: leave poison in this row's counter so everything behind it stops too (-1 failure, -2 abort) */
+            if (threadIdx.x == 0)
+            {
+                if (st == -1) *errflag = 1;
+                __hip_atomic_store(C.progress + row, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
         }
         STAMP(L, 13);
         row_step(L, G, C, T, row, x);
@@ -97,14 +151,14 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
         STAMP(L, 14);
     }
     row_end(L, G, C, row);
-}
-
-__global__ void __launch_bounds__(64) h264e_splice_kernel(h264e_geom_t G, const h264e_chain_dev_t *chains,
-                                                          const h264e_frame_task_t *tasks, int *stepflags)
-{
-    const h264e_frame_task_t &T = tasks[blockIdx.x];
-    if (!T.active) return;
-    finalize_frame(G, chains[T.chain], T, stepflags + 2*blockIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(C.progress + row, G.nmbx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* row buffer + meta complete */
+    }
 }
 
 #endif
@@ -166,6 +220,20 @@ static int dev_malloc(void **p, size_t n) { return hipMalloc(p, n ? n : 1) == hi
 static void dev_free(void *p) { if (p) (void)hipFree(p); }
 #endif
 
+#ifdef H264E_EMU
+static int host_malloc(void **p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : -1; }
+static void host_free(void *p) { free(p); }
+#else
+/* pinned, device-mapped, coherent host memory: the kernel writes results here while it runs, the host polls it */
+static int host_malloc(void **p, size_t n)
+{
+    if (hipHostMalloc(p, n ? n : 1, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return -1;
+    memset(*p, 0, n ? n : 1);
+    return 0;
+}
+static void host_free(void *p) { if (p) (void)hipHostFree(p); }
+#endif
+
 #define TASK_RING 128
 
 struct h264e_hip_pool
@@ -180,6 +248,14 @@ struct h264e_hip_pool
     int *progress_all;
     int *errflag;
     int *stepflags;                      /* [nchains][2]: {clusters_moved, overflow} of the last step, one read per step */
+    /* streaming: per chain slot, host-mapped result buffers the finalizer workgroups fill while the launch runs */
+    h264e_hostdone_t *host_done;         /* [nchains] */
+    uint8_t **host_rbsp;                 /* [nchains], each host_rbsp_cap bytes */
+    h264e_hip_mbrec_t **host_mbrec;      /* [nchains], each nmb records */
+    uint32_t host_rbsp_cap;
+    int *abort_word;                     /* host-mapped */
+    int launch_counter;
+    int *slot_launch;                    /* per chain slot: launch id of its current job */
     int32_t **clu_dev;                   /* per chain: optional per-macroblock mv_clusters array */
     int *ref_sel;                        /* per chain */
     int ring_pos, pending;
@@ -219,6 +295,10 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
             dev_free(C.mbrec); dev_free(C.arena); dev_free(C.cursor); dev_free(C.fout); dev_free(C.prof);
             if (p->clu_dev) dev_free(p->clu_dev[c]);
         }
+    if (p->host_rbsp) for (int c = 0; c < p->nchains; c++) host_free(p->host_rbsp[c]);
+    if (p->host_mbrec) for (int c = 0; c < p->nchains; c++) host_free(p->host_mbrec[c]);
+    host_free(p->host_done); host_free(p->abort_word);
+    free(p->host_rbsp); free(p->host_mbrec); free(p->slot_launch);
     dev_free(p->clip); dev_free(p->chains_dev); dev_free(p->tasks_dev); dev_free(p->progress_all); dev_free(p->errflag); dev_free(p->stepflags);
 #ifndef H264E_EMU
     if (p->stream)
@@ -264,6 +344,9 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     p->chains_host = (h264e_chain_dev_t *)calloc((size_t)nchains, sizeof(h264e_chain_dev_t));
     p->clu_dev = (int32_t **)calloc((size_t)nchains, sizeof(int32_t *));
     p->ref_sel = (int *)calloc((size_t)nchains, sizeof(int));
+    p->slot_launch = (int *)calloc((size_t)nchains, sizeof(int));
+    p->host_rbsp = (uint8_t **)calloc((size_t)nchains, sizeof(uint8_t *));
+    p->host_mbrec = (h264e_hip_mbrec_t **)calloc((size_t)nchains, sizeof(h264e_hip_mbrec_t *));
     int bad = 0;
     bad |= dev_malloc((void **)&p->clip, p->frame_bytes*(size_t)frames_resident);
     bad |= dev_malloc((void **)&p->chains_dev, sizeof(h264e_chain_dev_t)*(size_t)nchains);
@@ -273,6 +356,9 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     bad |= dev_malloc((void **)&p->stepflags, sizeof(int)*2*(size_t)nchains);
     const size_t plane = (size_t)G.W*G.H*3/2;
     const uint32_t arena_cap = (uint32_t)((size_t)slots*((size_t)G.nmb*640 + 1024));
+    p->host_rbsp_cap = (uint32_t)((size_t)G.nmb*640 + 1024);
+    bad |= host_malloc((void **)&p->host_done, sizeof(h264e_hostdone_t)*(size_t)nchains);
+    bad |= host_malloc((void **)&p->abort_word, 64);
     for (int c = 0; c < nchains && !bad; c++)
     {
         h264e_chain_dev_t &C = p->chains_host[c];
@@ -295,6 +381,11 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         bad |= dev_malloc((void **)&C.cursor, 16);
         bad |= dev_malloc((void **)&C.fout, sizeof(h264e_frameout_t)*(size_t)slots);
         bad |= dev_malloc((void **)&C.prof, sizeof(unsigned long long)*32);
+        if (slots == 1)        /* streaming pools keep one result per chain slot: give each a host-mapped mirror */
+        {
+            bad |= host_malloc((void **)&p->host_rbsp[c], p->host_rbsp_cap + 64);
+            bad |= host_malloc((void **)&p->host_mbrec[c], sizeof(h264e_hip_mbrec_t)*(size_t)G.nmb + 64);
+        }
     }
     if (bad)
     {
@@ -399,6 +490,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     h264e_frame_task_t *host = (h264e_frame_task_t *)calloc((size_t)p->nchains, sizeof(h264e_frame_task_t));
     if (!host) FAIL("out of host memory");
     int any = 0;
+    const int launch_id = ++p->launch_counter;
     for (int c = 0; c < p->nchains; c++)
     {
         const h264e_hip_task_t &t = tasks[c];
@@ -428,6 +520,15 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             }
             d.chain = t.slot;
             d.arena_reset = 1;
+            if (p->host_rbsp[t.slot] && p->host_mbrec[t.slot])
+            {
+                d.host_done = p->host_done + t.slot;
+                d.host_rbsp = p->host_rbsp[t.slot]; d.host_rbsp_cap = p->host_rbsp_cap;
+                d.host_mbrec = (h264e_mbrec_t *)p->host_mbrec[t.slot];
+                d.abort_word = p->abort_word;
+                p->host_done[t.slot].done = 0;
+                p->slot_launch[t.slot] = launch_id;
+            }
             for (int k = 0; k < 3; k++)
             {
                 d.dec[k] = p->chains_host[t.slot].rec[0][k];
@@ -464,6 +565,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             d.clusters_per_mb = p->clu_dev[cs];
         }
         memcpy(d.qdat, t.qdat, sizeof(d.qdat));
+        d.launch_id = launch_id;
     }
     if (!any) { free(host); return 0; }
     h264e_frame_task_t *slot = p->tasks_dev + (size_t)p->ring_pos*p->nchains;
@@ -486,6 +588,14 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             free(L);
         }
         finalize_frame(G, C, T, p->stepflags + 2*c);
+        if (T.host_done)
+        {
+            export_frame(G, C, T);
+            const h264e_frameout_t &F = C.fout[T.frame_slot];
+            T.host_done->nbytes = F.nbytes; T.host_done->all_skipped = F.all_skipped;
+            T.host_done->clusters_moved = F.clusters_moved; T.host_done->overflow = F.overflow;
+            T.host_done->done = T.launch_id;
+        }
     }
 #else
     HIPCHK(hipSetDevice(p->device));
@@ -496,11 +606,9 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     HIPCHK(hipMemsetAsync(p->progress_all, 0, sizeof(int)*(size_t)p->nchains*G.nmby, p->stream));
     const int pe = p->ev_pending;
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][0], p->stream));
-    hipLaunchKernelGGL(h264e_mb_kernel, dim3((unsigned)(p->nchains*G.nmby)), dim3(64), 0, p->stream,
-                       G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, p->nchains, p->errflag);
+    hipLaunchKernelGGL(h264e_mb_kernel, dim3((unsigned)(p->nchains*(G.nmby + 1))), dim3(64), 0, p->stream,
+                       G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, p->nchains, p->errflag, p->stepflags);
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][1], p->stream));
-    hipLaunchKernelGGL(h264e_splice_kernel, dim3((unsigned)p->nchains), dim3(64), 0, p->stream,
-                       G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, p->stepflags);
     HIPCHK(hipGetLastError());
     if (p->profile)
     {
@@ -521,6 +629,51 @@ extern "C" int h264e_hip_step_flags(h264e_hip_pool_t *p, int *flags /* [nchains]
     HIPCHK(hipMemcpy(flags, p->stepflags, sizeof(int)*2*(size_t)p->nchains, hipMemcpyDeviceToHost));
 #endif
     return 0;
+}
+
+/* ---- streaming results: valid for pools created with slots_per_chain == 1 and tasks submitted with stream_mode */
+
+extern "C" int h264e_hip_stream_done(h264e_hip_pool_t *p, int slot, h264e_hip_result_t *res)
+{
+    if (!p || slot < 0 || slot >= p->nchains || !p->host_rbsp[slot]) FAIL("stream_done: bad argument");
+    const volatile h264e_hostdone_t *d = p->host_done + slot;
+    const int v = d->done;
+    if (v == -p->slot_launch[slot]) return 2;               /* the job was aborted */
+    if (v != p->slot_launch[slot]) return 0;                /* not yet */
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (res) { res->nbytes = d->nbytes; res->all_skipped = d->all_skipped; res->clusters_moved = d->clusters_moved; res->overflow = d->overflow; }
+    return 1;
+}
+
+extern "C" const uint8_t *h264e_hip_stream_rbsp(h264e_hip_pool_t *p, int slot)
+{
+    return (p && slot >= 0 && slot < p->nchains) ? p->host_rbsp[slot] : 0;
+}
+
+extern "C" const h264e_hip_mbrec_t *h264e_hip_stream_mbrec(h264e_hip_pool_t *p, int slot)
+{
+    return (p && slot >= 0 && slot < p->nchains) ? p->host_mbrec[slot] : 0;
+}
+
+/* ask every job of the most recent submit to stop (the launch drains quickly; sync afterwards) */
+extern "C" int h264e_hip_stream_abort(h264e_hip_pool_t *p)
+{
+    if (!p || !p->abort_word) FAIL("stream_abort: bad argument");
+    __atomic_store_n(p->abort_word, p->launch_counter, __ATOMIC_RELEASE);
+    return 0;
+}
+
+/* 1 while work submitted to the pool is still running */
+extern "C" int h264e_hip_busy(h264e_hip_pool_t *p)
+{
+#ifdef H264E_EMU
+    (void)p;
+    return 0;
+#else
+    if (!p) return 0;
+    (void)hipSetDevice(p->device);
+    return hipStreamQuery(p->stream) == hipErrorNotReady;
+#endif
 }
 
 extern "C" int h264e_hip_result(h264e_hip_pool_t *p, int chain, int slot, h264e_hip_result_t *res)

@@ -30,6 +30,7 @@
 #else
 #define WAVE_FOR(l) for (int l = 0; l < 64; ++l)
 #endif
+struct uint4 { uint32_t x, y, z, w; };
 DEV void wave_sync() {}
 DEV int wave_lane() { return 0; }
 DEV int uni(int v) { return v; }

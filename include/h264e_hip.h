@@ -67,6 +67,15 @@ int  h264e_hip_submit(h264e_hip_pool_t *pool, const h264e_hip_task_t *tasks /* [
 int  h264e_hip_sync(h264e_hip_pool_t *pool);
 /* {clusters_moved, overflow} of every chain for the LAST submitted step, in one copy (call after h264e_hip_sync) */
 int  h264e_hip_step_flags(h264e_hip_pool_t *pool, int *flags /* [nchains][2] */);
+/* streaming (pools with slots_per_chain == 1, tasks with stream_mode): every job has a finalizer inside the launch that
+ * copies its RBSP and macroblock records to host-mapped memory and raises a done word, so the host can consume frame
+ * after frame while later frames of the same launch are still running.
+ * h264e_hip_stream_done: 0 not finished, 1 finished (res filled), 2 aborted. */
+int  h264e_hip_stream_done(h264e_hip_pool_t *pool, int slot, h264e_hip_result_t *res);
+const uint8_t *h264e_hip_stream_rbsp(h264e_hip_pool_t *pool, int slot);
+const h264e_hip_mbrec_t *h264e_hip_stream_mbrec(h264e_hip_pool_t *pool, int slot);
+int  h264e_hip_stream_abort(h264e_hip_pool_t *pool);
+int  h264e_hip_busy(h264e_hip_pool_t *pool);
 int  h264e_hip_result(h264e_hip_pool_t *pool, int chain, int slot, h264e_hip_result_t *res);
 int  h264e_hip_read_rbsp(h264e_hip_pool_t *pool, int chain, int slot, uint8_t *dst, uint32_t cap);
 /* all results of a chain in two copies: per-slot result + byte offset into arena_dst, which receives the used part of the arena */
