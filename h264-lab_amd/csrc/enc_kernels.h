@@ -164,16 +164,34 @@ DEV void rv_wait_rect(const RefView &V, int x1, int y1)
 #endif
 }
 
-/* one lane per window row, 16 dword loads in flight per lane */
+/* one lane per window row: four 16-byte loads when the window's columns lie inside the picture (uniform test),
+ * clamped dword loads at the picture's left/right border */
 DEV void wave_load_window(uint8_t *win, const Plane &P, int wx0, int wy0)
 {
+    const bool interior = wx0 >= 0 && wx0 + WIN_W <= P.w;
     WAVE_FOR(l)
     {
-        uint32_t v[WIN_W/4];
+        const int y = imin(imax(wy0 + l, 0), P.h - 1);
+        if (interior)
+        {
+            const GLOBAL_AS u32x4 *src = (const GLOBAL_AS u32x4 *)(P.p + (size_t)y*P.stride + wx0);   /* wx0 is a multiple of 8: dword aligned */
+            u32x4 v[WIN_W/16];
 #pragma unroll
-        for (int g = 0; g < WIN_W/4; g++) v[g] = ref_load4(P, wx0 + 4*g, wy0 + l);
+            for (int g = 0; g < WIN_W/16; g++) v[g] = src[g];
 #pragma unroll
-        for (int g = 0; g < WIN_W/4; g++) lds32_store(win + l*WIN_STRIDE + 4*g, v[g]);
+            for (int g = 0; g < WIN_W/16; g++)
+            {
+                lds32_store(win + l*WIN_STRIDE + 16*g, v[g].x); lds32_store(win + l*WIN_STRIDE + 16*g + 4, v[g].y);
+                lds32_store(win + l*WIN_STRIDE + 16*g + 8, v[g].z); lds32_store(win + l*WIN_STRIDE + 16*g + 12, v[g].w);
+            }
+        } else
+        {
+            uint32_t v[WIN_W/4];
+#pragma unroll
+            for (int g = 0; g < WIN_W/4; g++) v[g] = ref_load4(P, wx0 + 4*g, y);
+#pragma unroll
+            for (int g = 0; g < WIN_W/4; g++) lds32_store(win + l*WIN_STRIDE + 4*g, v[g]);
+        }
     }
     wave_sync();
 }
@@ -189,14 +207,14 @@ DEV int wave_sad_ref(const RefView &R, int x0, int y0, const uint8_t *b, int w, 
         const lu8 *base = rv_ptr(R, x0, y0);
         return wave_sum([&](int l) -> int {
             if (l >= n) return 0;
-            int r = l/g, c = l - r*g;
+            int r = l >> (g >> 1), c = l & (g - 1);              /* g is 2 or 4 */
             return (int)sad4_u8(lds32u(base + r*WIN_STRIDE + 4*c), lds32(b + 16*r + 4*c), 0);
         });
     }
     rv_wait_rect(R, x0 + w - 1, y0 + h - 1);
     return wave_sum([&](int l) -> int {
         if (l >= n) return 0;
-        int r = l/g, c = l - r*g;
+        int r = l >> (g >> 1), c = l & (g - 1);              /* g is 2 or 4 */
         return (int)sad4_u8(ref_load4(R.P, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
     });
 }
@@ -227,7 +245,7 @@ DEV int wave_sad_lds(const uint8_t *a, const uint8_t *b, int w, int h)
     const int g = w >> 2, n = g*h;
     return wave_sum([&](int l) -> int {
         if (l >= n) return 0;
-        int r = l/g, c = l - r*g;
+        int r = l >> (g >> 1), c = l & (g - 1);              /* g is 2 or 4 */
         return (int)sad4_u8(lds32(a + 16*r + 4*c), lds32(b + 16*r + 4*c), 0);
     });
 }
@@ -356,7 +374,7 @@ DEV void wave_interp_luma(const RefView &R, int bx, int by, mv32 mv, int w, int 
     {
         if (l < n)
         {
-            int r = l/g, c = l - r*g;
+            int r = l >> (g >> 1), c = l & (g - 1);              /* g is 2 or 4 */
             lds32_store(dst + 16*r + 4*c, interp_luma4(R, inside, ix + 4*c, iy + r, fx, fy));
         }
     }
@@ -371,7 +389,7 @@ DEV void wave_avg(const uint8_t *a, const uint8_t *b, uint8_t *d, int w, int h)
     {
         if (l < n)
         {
-            int r = l/g, c = l - r*g;
+            int r = l >> (g >> 1), c = l & (g - 1);              /* g is 2 or 4 */
             uint32_t x = lds32(a + 16*r + 4*c), y = lds32(b + 16*r + 4*c), o = 0;
             for (int k = 0; k < 4; k++) o |= ((((x >> (8*k)) & 255) + ((y >> (8*k)) & 255) + 1) >> 1) << (8*k);
             lds32_store(d + 16*r + 4*c, o);
@@ -387,7 +405,7 @@ DEV void wave_copy_wh(uint8_t *d, const uint8_t *s, int w, int h)
     {
         if (l < n)
         {
-            int r = l/g, c = l - r*g;
+            int r = l >> (g >> 1), c = l & (g - 1);              /* g is 2 or 4 */
             lds32_store(d + 16*r + 4*c, lds32(s + 16*r + 4*c));
         }
     }
@@ -587,7 +605,7 @@ DEV unsigned wave_xform_quant(const uint8_t *inp, const uint8_t *pred, int mode,
             const int idx = pass*64 + l, b = idx >> 4, i = idx & 15;
             if (b < nb)
             {
-                const int kh = i >> 2, kv = i & 3, bx = b % n, by = b / n;
+                const int kh = i >> 2, kv = i & 3, bx = b & (n - 1), by = b >> (n >> 1);      /* n is 1, 2 or 4 */
                 const uint8_t *pi = inp + 64*by + 4*bx, *pp = pred + 64*by + 4*bx;
                 int rr[4];
 #pragma unroll
@@ -744,7 +762,7 @@ DEV void wave_recon(uint8_t *out, int os, const uint8_t *pred, const qblk_t *q, 
             int idx = pass*64 + l, b = idx >> 4, i = idx & 15;
             if (b < nb)
             {
-                int x = i & 3, y = i >> 2, bx = b % side, by = b / side;
+                int x = i & 3, y = i >> 2, bx = b & (side - 1), by = b >> (side >> 1);          /* side is 1, 2 or 4 */
                 int v = pred[64*by + 4*bx + 16*y + x];
                 if ((mask << b) & 0x80000000u)
                 {

@@ -170,9 +170,9 @@ DEV void set_range(mv32 &pnt, rect_t &range, const rect_t &limit, int mby_q)
  * H:4973-5176 me_search_diamond for the w x h partition at (px,py) of the macroblock; mv is absolute for
  * the macroblock (quarter-pel), so the block sits at (px,py) + (mv >> 2) in the reference picture.
  * The uint16 SAD cache with its 0xffff sentinel is observable behaviour.
- * L.blk receives the prediction of the returned vector.
+ * dst (LDS, stride 16) receives the prediction of the returned vector.
  */
-DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_t &range, mv32 mv_pred, int min_sad, int w, int h)
+DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_t &range, mv32 mv_pred, int min_sad, int w, int h, uint8_t *dst)
 {
     const RefView &R = m.rv;
     const uint8_t *b = L.inp + 16*py + px;
@@ -217,7 +217,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
                         const lu8 *base = rv_ptr(R, cx, cy);
                         wave_sum4([&](int l, int *sv) {
                             if (l >= n) return;
-                            const int r = l/g, c4 = l - r*g;
+                            const int r = l >> (g >> 1), c4 = l & (g - 1);
                             const uint32_t in4 = lds32(b + 16*r + 4*c4);
                             const lu8 *p = base + r*WIN_STRIDE + 4*c4;
                             if (want & 1) sv[0] = (int)sad4_u8(lds32u(p + 1), in4, 0);
@@ -230,7 +230,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
                         rv_wait_rect(R, cx + w, cy + h);
                         wave_sum4([&](int l, int *sv) {
                             if (l >= n) return;
-                            const int r = l/g, c4 = l - r*g;
+                            const int r = l >> (g >> 1), c4 = l & (g - 1);
                             const uint32_t in4 = lds32(b + 16*r + 4*c4);
                             if (want & 1) sv[0] = (int)sad4_u8(ref_load4(R.P, cx + 4*c4 + 1, cy + r), in4, 0);
                             if (want & 2) sv[1] = (int)sad4_u8(ref_load4(R.P, cx + 4*c4 - 1, cy + r), in4, 0);
@@ -287,7 +287,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
     STAMP(L, 5);
     if (!(m.T->speed < 9 && in_rect(mv, mv_qlimit(m))))
     {
-        wave_interp_luma(R, px, py, mv, w, h, L.blk);
+        wave_interp_luma(R, px, py, mv, w, h, dst);
         STAMP(L, 6);
         return min_sad;
     }
@@ -310,7 +310,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
         if (!inside) rv_wait_rect(R, fx0 + w + 4, fy0 + h + 3);
         wave_sum8([&](int l, int *sv) {
             if (l >= n) return;
-            const int r = l/g, c4 = l - r*g, o = 16*r + 4*c4;
+            const int r = l >> (g >> 1), c4 = l & (g - 1), o = 16*r + 4*c4;
             const uint32_t in4 = lds32(b + o);
 #define IP(vv) interp_luma4(R, inside, px + (mvx(vv) >> 2) + 4*c4, py + (mvy(vv) >> 2) + r, mvx(vv) & 3, mvy(vv) & 3)
 #define AVG4(x, y) (((x) | (y)) - ((((x) ^ (y)) >> 1) & 0x7f7f7f7fu))                    /* per-byte (x + y + 1) >> 1 */
@@ -334,7 +334,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
 #undef TRY
         const uint8_t *src = best < 0 ? L.p00 : best == 0 ? L.p02 : best == 1 ? L.skip_tmp[0] : best == 2 ? L.p20 : best == 3 ? L.skip_tmp[1] :
                              best == 4 ? L.skip_tmp[2] : best == 5 ? L.p22 : L.skip_tmp[3];
-        wave_copy_wh(L.blk, src, w, h);
+        wave_copy_wh(dst, src, w, h);
         mv = vbest;
     }
     STAMP(L, 6);
@@ -512,11 +512,10 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
                 sad_best = wave_sad_ref(R, px + (mvx(mvabs) >> 2), py + (mvy(mvabs) >> 2), L.inp + 16*py + px, w, h)
                          + mv_cost(m, mvabs, mb_abs(m, mvp));
             }
-            part_sad += diamond(L, m, px, py, mvabs, range, mb_abs(m, mvp), sad_best, w, h);
+            part_sad += diamond(L, m, px, py, mvabs, range, mb_abs(m, mvp), sad_best, w, h, L.test + 16*py + px);
             /* the partition costs only add up: once they reach the best cost so far this partitioning cannot win (H:5500 is a
              * strict "<"), and nothing else of it is observable -- the predictor context is restored below */
             if (part_sad >= m.cost) { lost = 1; break; }
-            wave_copy_wh(L.test + 16*py + px, L.blk, w, h);
             const mv32 mv = mvsub(mvabs, mvmk(m.x*64, m.y*64));
             L.part_mvd[t][imv] = mvsub(mv, mvp);
             L.part_mv[t][imv++] = mv;

@@ -421,15 +421,15 @@ DEV void export_frame(const h264e_geom_t &G, const h264e_chain_dev_t &C, const h
 {
     const h264e_frameout_t &F = C.fout[T.frame_slot];
     const uint32_t nb = imin((int)F.nbytes, (int)T.host_rbsp_cap), nw = (nb + 15u) >> 4;
-    const uint4 *src = (const uint4 *)(C.arena + F.offset);
-    uint4 *dst = (uint4 *)T.host_rbsp;
+    const u32x4 *src = (const u32x4 *)(C.arena + F.offset);
+    u32x4 *dst = (u32x4 *)T.host_rbsp;
     for (uint32_t base = 0; base < nw; base += 64)
     {
         WAVE_FOR(l) { if (base + (uint32_t)l < nw) dst[base + l] = src[base + l]; }
     }
     const uint32_t nr = ((uint32_t)G.nmb*(uint32_t)sizeof(h264e_mbrec_t) + 15u) >> 4;
-    const uint4 *rs = (const uint4 *)(C.mbrec + (size_t)T.frame_slot*G.nmb);
-    uint4 *rd = (uint4 *)T.host_mbrec;
+    const u32x4 *rs = (const u32x4 *)(C.mbrec + (size_t)T.frame_slot*G.nmb);
+    u32x4 *rd = (u32x4 *)T.host_mbrec;
     for (uint32_t base = 0; base < nr; base += 64)
     {
         WAVE_FOR(l) { if (base + (uint32_t)l < nr) rd[base + l] = rs[base + l]; }

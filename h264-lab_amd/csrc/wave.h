@@ -30,7 +30,7 @@
 #else
 #define WAVE_FOR(l) for (int l = 0; l < 64; ++l)
 #endif
-struct uint4 { uint32_t x, y, z, w; };
+struct u32x4 { uint32_t x, y, z, w; };
 DEV void wave_sync() {}
 DEV int wave_lane() { return 0; }
 DEV int uni(int v) { return v; }
@@ -89,6 +89,7 @@ DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 #define DEV static __device__ __forceinline__
 #define DCONST static __device__ const
 #define WAVE_FOR(l) for (int l = (int)threadIdx.x, _w1 = 1; _w1; _w1 = 0)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 /* Single-wave workgroup: LDS operations of one wavefront execute in program order, so making one lane's LDS
  * store visible to another lane only needs the COMPILER to keep the order: a wavefront-scope fence (no
  * instruction) plus a wave barrier (keeps the lanes converged across it). */
