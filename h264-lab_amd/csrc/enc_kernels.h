@@ -48,7 +48,7 @@ struct BitW
     uint32_t pos;       /* words written */
     uint32_t cap;       /* capacity in words */
     int overflow;
-    uint32_t *buf;      /* global memory: MSB-first 32-bit words */
+    GLOBAL_AS uint32_t *buf;    /* global memory: MSB-first 32-bit words */
 };
 
 /* H:2688-2702: append n <= 32 bits.  Uniform: all lanes hold the same state and store the same word. */
@@ -125,7 +125,7 @@ DEV uint32_t lds32u(const lu8 *p)
 struct RefView
 {
     Plane P; const lu8 *win; int has_win, wx0, wy0;
-    const int *dep;             /* progress counters of the frame being referenced while it is still being encoded (temporal wavefront) */
+    const GLOBAL_AS int *dep;   /* progress counters of the frame being referenced while it is still being encoded (temporal wavefront) */
     int nmbx, nmby;
 };
 
@@ -149,10 +149,12 @@ DEV void rv_wait_rect(const RefView &V, int x1, int y1)
     if (!V.dep) return;
     const int X = imin(imax(x1, 0), V.P.w - 1) >> 4, Y = imin(imax(y1, 0), V.P.h - 1) >> 4;
     const int drow = imin(Y + 1, V.nmby - 1), need = imin(X + 2, V.nmbx);
-    const int *flag = V.dep + drow;
+    const GLOBAL_AS int *flag = V.dep + drow;
     unsigned spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need)
+    for (;;)
     {
+        const int seen = uni(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));      /* uni: scalar loop control */
+        if (seen >= need || seen < 0) break;        /* negative = the producer stopped (abort / failure): this row stops at its next macroblock */
         if (++spins > (1u << 24)) break;            /* bounded: a stuck producer is reported by its own row loop */
         __builtin_amdgcn_s_sleep(8);
     }

@@ -172,9 +172,10 @@ DEV void set_range(mv32 &pnt, rect_t &range, const rect_t &limit, int mby_q)
  * The uint16 SAD cache with its 0xffff sentinel is observable behaviour.
  * dst (LDS, stride 16) receives the prediction of the returned vector.
  */
-DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_t &range, mv32 mv_pred, int min_sad, int w, int h, uint8_t *dst)
+DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_t &range_, mv32 mv_pred, int min_sad, int w, int h, uint8_t *dst)
 {
     const RefView &R = m.rv;
+    const rect_t range = { uni(range_.x0), uni(range_.y0), uni(range_.x1), uni(range_.y1) };    /* scalar registers: the scan below is scalar control code */
     const uint8_t *b = L.inp + 16*py + px;
     /* the reference's uint16 cache[8]: four 16-bit fields each in `cur` (neighbours of the centre) and `prv` */
     uint64_t cur, prv;
@@ -185,6 +186,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
     int dir, cloop, dir_prev, cost;
     mv32 v;
     mv = (mv32)uni(mv); mv_pred = (mv32)uni(mv_pred); min_sad = uni(min_sad);
+    px = uni(px); py = uni(py); w = uni(w); h = uni(h);
     const int g = w >> 2, n = g*h;
     PCOUNT(L, 18);
     for (;;)
@@ -451,7 +453,7 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
     if (m.x <= 0) L.cand[ncand++] = mvmk(8*4, 0);
     if (m.y <= 0) L.cand[ncand++] = mvmk(0, 8*4);
     {
-        const mv32 *clu = m.T->clusters_per_mb ? m.T->clusters_per_mb + 2*m.num : m.T->clusters;
+        const GLOBAL_AS mv32 *clu = m.T->clusters_per_mb ? (const GLOBAL_AS mv32 *)m.T->clusters_per_mb + 2*m.num : (const GLOBAL_AS mv32 *)m.T->clusters;
         L.cand[ncand++] = clu[0];
         L.cand[ncand++] = clu[1];
     }

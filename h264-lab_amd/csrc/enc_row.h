@@ -12,7 +12,32 @@
 
 #include "enc_mb.h"
 
-DEV void row_begin(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, const h264e_frame_task_t &T, int row)
+/* the chain's buffers with explicit HBM address spaces (pointers loaded from a struct are generic otherwise: FLAT
+ * instructions, and the compiler has to treat what they load as lane-varying) */
+struct ChainG
+{
+    GLOBAL_AS h264e_mbbottom_t *bottom;
+    GLOBAL_AS int *progress;
+    GLOBAL_AS uint32_t *rowbits;
+    GLOBAL_AS h264e_rowmeta_t *rowmeta;
+    GLOBAL_AS h264e_mbrec_t *mbrec;
+    GLOBAL_AS uint8_t *arena;
+    uint32_t arena_cap;
+    GLOBAL_AS uint32_t *cursor;
+    GLOBAL_AS h264e_frameout_t *fout;
+    unsigned long long *prof;
+};
+DEV ChainG chain_view(const h264e_chain_dev_t &C)
+{
+    ChainG g;
+    g.bottom = (GLOBAL_AS h264e_mbbottom_t *)C.bottom; g.progress = (GLOBAL_AS int *)C.progress;
+    g.rowbits = (GLOBAL_AS uint32_t *)C.rowbits; g.rowmeta = (GLOBAL_AS h264e_rowmeta_t *)C.rowmeta;
+    g.mbrec = (GLOBAL_AS h264e_mbrec_t *)C.mbrec; g.arena = (GLOBAL_AS uint8_t *)C.arena; g.arena_cap = C.arena_cap;
+    g.cursor = (GLOBAL_AS uint32_t *)C.cursor; g.fout = (GLOBAL_AS h264e_frameout_t *)C.fout; g.prof = C.prof;
+    return g;
+}
+
+DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, int row)
 {
     WAVE_FOR(l)
     {
@@ -43,13 +68,13 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C,
 }
 
 /* neighbour record of the macroblock above -> LDS (h264-lab.h:742-745 contexts, :590-606 deblock state) */
-DEV void load_top(RowLds &L, const h264e_geom_t &G, const h264e_mbbottom_t *above, int x, int have_top)
+DEV void load_top(RowLds &L, const h264e_geom_t &G, const GLOBAL_AS h264e_mbbottom_t *above, int x, int have_top)
 {
     WAVE_FOR(l)
     {
         if (have_top)
         {
-            const h264e_mbbottom_t &B = above[x];
+            const GLOBAL_AS h264e_mbbottom_t &B = above[x];
             if (l < 8) L.pix_top[4*l + 0] = B.pix[4*l + 0], L.pix_top[4*l + 1] = B.pix[4*l + 1], L.pix_top[4*l + 2] = B.pix[4*l + 2], L.pix_top[4*l + 3] = B.pix[4*l + 3];
             else if (l < 12) L.mv_top[l - 8] = B.mv[l - 8];
             else if (l < 20) L.nnz_top[l - 12] = B.nnz[l - 12];
@@ -96,7 +121,7 @@ DEV void load_input(RowLds &L, const h264e_geom_t &G, const h264e_frame_task_t &
     wave_sync();
 }
 
-DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, const h264e_frame_task_t &T, int row, int x)
+DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, int row, int x)
 {
     MbCtx m;
     m.G = &G; m.T = &T;
@@ -114,11 +139,11 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
     m.lambda_mv = uni((int)k_lambda_mv_q4[T.qp]); m.lambda_q4 = uni((int)k_lambda_q4[T.qp]); m.skip_thr = uni((int)k_skip_thr_inter[T.qp]);
     m.skip_thr_i4 = uni((int)k_skip_thr_i4x4[T.qp]); m.lambda_i4 = uni((int)k_lambda_i4_q4[T.qp]); m.lambda_i16 = uni((int)k_lambda_i16_q4[T.qp]);
 
-    h264e_mbbottom_t *rowrec = C.bottom + (size_t)row*G.nmbx;
+    GLOBAL_AS h264e_mbbottom_t *rowrec = C.bottom + (size_t)row*G.nmbx;
     STAMP(L, 0);
     load_top(L, G, rowrec - G.nmbx, x, row > 0);
     load_input(L, G, T, x, row);
-    m.rv.dep = T.dep_progress; m.rv.nmbx = G.nmbx; m.rv.nmby = G.nmby;
+    m.rv.dep = (const GLOBAL_AS int *)T.dep_progress; m.rv.nmbx = G.nmbx; m.rv.nmby = G.nmby;
     m.rv.P = m.ref[0]; m.rv.win = (const lu8 *)L.win; m.rv.has_win = 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
     if (T.slice_type == 0)
     {
@@ -148,7 +173,7 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
 
     /* record for the mv_clusters validation (h264-lab.h:5776-5779 updates them with mv[0] of every non-intra MB) */
     {
-        h264e_mbrec_t *rec = C.mbrec + (size_t)T.frame_slot*G.nmb + m.num;
+        GLOBAL_AS h264e_mbrec_t *rec = C.mbrec + (size_t)T.frame_slot*G.nmb + m.num;
         rec->mv0 = m.type < 5 ? L.mv[0] : 0;
         rec->type = (int8_t)m.type;
         rec->used_cand = (uint8_t)m.used_cand;
@@ -157,7 +182,7 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
     /* keep the UNFILTERED right column / bottom row for intra prediction (h264-lab.h:4693-4714) */
     uint8_t *ty = L.ytile + 4*YT_STRIDE + 4;
     uint8_t *tc0 = L.ctile[0] + 2*CT_STRIDE + 2, *tc1 = L.ctile[1] + 2*CT_STRIDE + 2;
-    h264e_mbbottom_t &B = rowrec[x];
+    GLOBAL_AS h264e_mbbottom_t &B = rowrec[x];
     WAVE_FOR(l)
     {
         if (l < 16)
@@ -272,7 +297,7 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, 
     L.prof[20 + (m.type < 0 ? 0 : m.type < 5 ? 1 : 2)]++;
 }
 
-DEV void row_end(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, int row)
+DEV void row_end(RowLds &L, const h264e_geom_t &G, const ChainG &C, int row)
 {
     BitW bw = L.bw;
     const uint32_t nbits = bw_bits(bw);
@@ -281,7 +306,7 @@ DEV void row_end(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, i
         const int pad = 32 - bw.nacc;
         bw_put(bw, pad, 0);
     }
-    h264e_rowmeta_t &M = C.rowmeta[row];
+    GLOBAL_AS h264e_rowmeta_t &M = C.rowmeta[row];
     M.nbits = nbits;
     M.lead_skips = L.coded_any ? L.lead_skips : G.nmbx;
     M.trail_skips = L.coded_any ? L.skip_run : 0;
@@ -294,7 +319,7 @@ DEV void row_end(RowLds &L, const h264e_geom_t &G, const h264e_chain_dev_t &C, i
 
 /* ------------------------------------------------------------------ slice splice (one wavefront per chain) */
 
-struct SpliceState { uint32_t *out; uint32_t wpos; uint32_t carry; int cbits; uint32_t cap_words; int overflow; };
+struct SpliceState { GLOBAL_AS uint32_t *out; uint32_t wpos; uint32_t carry; int cbits; uint32_t cap_words; int overflow; };
 
 /* append nbits (<= 64) right-aligned bits */
 DEV void splice_put(SpliceState &s, int nbits, uint64_t v)
@@ -316,7 +341,7 @@ DEV void splice_put(SpliceState &s, int nbits, uint64_t v)
 }
 
 /* append the first nbits of an MSB-first word buffer, 64 words per pass */
-DEV void splice_words(SpliceState &s, const uint32_t *w, uint32_t nbits)
+DEV void splice_words(SpliceState &s, const GLOBAL_AS uint32_t *w, uint32_t nbits)
 {
     const uint32_t nfull = nbits >> 5;
     const int cb = s.cbits;
@@ -358,18 +383,18 @@ DEV void clusters_step(mv32 c[2], mv32 mv)                                  /* h
     if (n >= n0) c[1] = mvmk((63*mvx(c[1]) + mvx(mv) + 32) >> 6, (63*mvy(c[1]) + mvy(mv) + 32) >> 6);
 }
 
-DEV void finalize_frame(const h264e_geom_t &G, const h264e_chain_dev_t &C, const h264e_frame_task_t &T, int *stepflags)
+DEV void finalize_frame(const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, GLOBAL_AS int *stepflags)
 {
     SpliceState s;
     const uint32_t start = T.arena_reset ? 0u : ((*C.cursor + 3u) & ~3u);
-    s.out = (uint32_t *)(C.arena + start);
+    s.out = (GLOBAL_AS uint32_t *)(C.arena + start);
     s.wpos = 0; s.carry = 0; s.cbits = 0; s.overflow = 0;
     s.cap_words = (C.arena_cap - start) >> 2;
     splice_put(s, T.hdr_nbits, T.hdr_bits);
     int run = 0, overflow = 0;
     for (int row = 0; row < G.nmby; row++)
     {
-        const h264e_rowmeta_t &M = C.rowmeta[row];
+        const GLOBAL_AS h264e_rowmeta_t &M = C.rowmeta[row];
         overflow |= M.overflow;
         run += M.lead_skips;
         if (M.lead_skips < G.nmbx || M.nbits)
@@ -388,7 +413,7 @@ DEV void finalize_frame(const h264e_geom_t &G, const h264e_chain_dev_t &C, const
     if (s.cbits) { int pad = 32 - s.cbits; splice_put(s, pad, 0); }
 
     /* mv_clusters speculation check: is the speculated state a fixed point of every update of this frame? */
-    const h264e_mbrec_t *rec = C.mbrec + (size_t)T.frame_slot*G.nmb;
+    const GLOBAL_AS h264e_mbrec_t *rec = C.mbrec + (size_t)T.frame_slot*G.nmb;
     int moved = 0;
     if (!T.clusters_per_mb)
     {
@@ -404,7 +429,7 @@ DEV void finalize_frame(const h264e_geom_t &G, const h264e_chain_dev_t &C, const
             if (bad) moved = 1;
         }
     }
-    h264e_frameout_t &F = C.fout[T.frame_slot];
+    GLOBAL_AS h264e_frameout_t &F = C.fout[T.frame_slot];
     F.offset = start;
     F.nbytes = nbytes;
     F.all_skipped = all_skipped;
@@ -417,19 +442,19 @@ DEV void finalize_frame(const h264e_geom_t &G, const h264e_chain_dev_t &C, const
 }
 
 /* copy the finished frame's RBSP and macroblock records into host-mapped memory (16 bytes per lane per pass) */
-DEV void export_frame(const h264e_geom_t &G, const h264e_chain_dev_t &C, const h264e_frame_task_t &T)
+DEV void export_frame(const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T)
 {
-    const h264e_frameout_t &F = C.fout[T.frame_slot];
+    const GLOBAL_AS h264e_frameout_t &F = C.fout[T.frame_slot];
     const uint32_t nb = imin((int)F.nbytes, (int)T.host_rbsp_cap), nw = (nb + 15u) >> 4;
-    const u32x4 *src = (const u32x4 *)(C.arena + F.offset);
-    u32x4 *dst = (u32x4 *)T.host_rbsp;
+    const GLOBAL_AS u32x4 *src = (const GLOBAL_AS u32x4 *)(C.arena + F.offset);
+    GLOBAL_AS u32x4 *dst = (GLOBAL_AS u32x4 *)T.host_rbsp;
     for (uint32_t base = 0; base < nw; base += 64)
     {
         WAVE_FOR(l) { if (base + (uint32_t)l < nw) dst[base + l] = src[base + l]; }
     }
     const uint32_t nr = ((uint32_t)G.nmb*(uint32_t)sizeof(h264e_mbrec_t) + 15u) >> 4;
-    const u32x4 *rs = (const u32x4 *)(C.mbrec + (size_t)T.frame_slot*G.nmb);
-    u32x4 *rd = (u32x4 *)T.host_mbrec;
+    const GLOBAL_AS u32x4 *rs = (const GLOBAL_AS u32x4 *)(C.mbrec + (size_t)T.frame_slot*G.nmb);
+    GLOBAL_AS u32x4 *rd = (GLOBAL_AS u32x4 *)T.host_mbrec;
     for (uint32_t base = 0; base < nr; base += 64)
     {
         WAVE_FOR(l) { if (base + (uint32_t)l < nr) rd[base + l] = rs[base + l]; }

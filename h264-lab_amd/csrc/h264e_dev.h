@@ -18,6 +18,14 @@
 #define H264E_MV_NA 0x8000
 #define H264E_ROW_BYTES_PER_MB 2048     /* capacity of a row bit buffer, per macroblock of the row */
 
+/* Temporal wavefront (a P frame starts while its reference frame is still being encoded): macroblock (x, row) needs the
+ * reference window x*16-24 .. x*16+39 by row*16-24 .. row*16+39 reconstructed AND deblocked.  Its last sample lies in
+ * macroblock (x+2, row+2) at local (7,7): outside the 3 right columns / bottom rows that the neighbours to the right
+ * and below still filter, so it is final once row+2 of the reference frame has published x+3 macroblocks. */
+#define H264E_DEP_ROWS 2
+#define H264E_DEP_COLS 3
+#define H264E_FRAME_LAG (2*H264E_DEP_ROWS + H264E_DEP_COLS)    /* macroblock steps between consecutive frames' starts */
+
 typedef int32_t mv32;                   /* packed (y << 16) | (x & 0xffff), quarter-pel */
 
 typedef struct

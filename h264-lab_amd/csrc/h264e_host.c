@@ -815,6 +815,8 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
         }
         stats.rounds++;
         have_after = 0;
+        const double t_submit = now_ms();
+        double t_first = 0, t_last = 0;
         if (h264e_hip_submit(c->pool, tasks)) goto done;
 
         /* consume the frames in stream order while the launch is still running */
@@ -836,6 +838,8 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
                 if (!g_host_err[0] && !h264e_hip_last_error()[0]) snprintf(g_host_err, sizeof(g_host_err), "frame %d did not complete", f);
                 goto done;
             }
+            t_last = now_ms();
+            if (i == 0) t_first = t_last;
             if (r1.overflow) { snprintf(g_host_err, sizeof(g_host_err), "bit buffer overflow (frame %d)", f); (void)h264e_hip_stream_abort(c->pool); (void)h264e_hip_sync(c->pool); goto done; }
             if (per_mb || r1.clusters_moved || used[i][0] != state[0] || used[i][1] != state[1])
             {
@@ -871,7 +875,9 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
         if (h264e_hip_sync(c->pool)) goto done;         /* the launch has drained (immediately after an abort) */
         stats.encode_ms += now_ms() - t0;
         n += nvalid;
-        if (getenv("H264E_DEBUG")) fprintf(stderr, "clip launch %d: %d frames in flight, %d valid, next %d\n", stats.rounds, F, nvalid, n);
+        if (getenv("H264E_DEBUG"))
+            fprintf(stderr, "clip launch %d: %d frames in flight, %d valid, next %d; first frame after %.2f ms, then %.3f ms/frame, drained %.2f ms after the last\n",
+                    stats.rounds, F, nvalid, n, t_first - t_submit, nvalid > 1 ? (t_last - t_first)/(nvalid - 1 + (nvalid < F)) : 0.0, now_ms() - t_last);
     }
     stats.mv_clusters_out[0] = state[0]; stats.mv_clusters_out[1] = state[1];
     stats.next_idr_pic_id_state = idr_state ^ (((c->nframes + G - 1)/G) & 1);

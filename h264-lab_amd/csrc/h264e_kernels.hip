@@ -35,12 +35,12 @@ extern "C" const char *h264e_hip_last_error(void) { return g_err; }
 
 /* relaxed poll of one progress counter until it reaches `need`.  Returns 0 = reached, -1 = producer failed or the
  * bound expired, -2 = producer was aborted (negative counters are poison left behind by a row that stopped). */
-DEV int poll_progress(const int *flag, int need, int &seen)
+DEV int poll_progress(const GLOBAL_AS int *flag, int need, int &seen)
 {
     unsigned spins = 0;
     for (;;)
     {
-        seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seen = uni(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));     /* uni: the loop control is scalar */
         if (seen >= need) return 0;
         if (seen < 0) return seen;
         if (++spins > SPIN_LIMIT) return -1;
@@ -49,7 +49,7 @@ DEV int poll_progress(const int *flag, int need, int &seen)
 }
 
 /*
- * Grid: njobs x (nmby + 1) workgroups of one wavefront, job-major.  Workgroup `row < nmby` encodes macroblock row
+ * Grid: njobs x (nmby + 1) workgroups of one wavefront.  Workgroup `row < nmby` encodes macroblock row
  * `row` of its job's frame; workgroup `nmby` is the job's finalizer: once every row has ended it splices the slice
  * (finalize_frame) and, in streaming use, exports the result to host-mapped memory and raises the job's done word,
  * so the host consumes frames while later frames of the same launch are still being encoded.
@@ -57,14 +57,16 @@ DEV int poll_progress(const int *flag, int need, int &seen)
  * rows of the own job for the finalizer).
  */
 __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h264e_chain_dev_t *chains,
-                                                         const h264e_frame_task_t *tasks, int njobs, int *errflag, int *stepflags)
+                                                         const h264e_frame_task_t *tasks, const uint32_t *order, int *errflag, int *stepflags)
 {
     __shared__ RowLds L;
-    const int job = (int)(blockIdx.x / (unsigned)(G.nmby + 1)), row = (int)(blockIdx.x % (unsigned)(G.nmby + 1));
-    (void)njobs;
+    /* workgroups are dispatched in index order: `order` lists (job, row) by the step at which the row can start
+     * (H264E_FRAME_LAG*job + 2*row), so the resident workgroups are the ones that can make progress */
+    const uint32_t jr = order[blockIdx.x];
+    const int job = (int)(jr >> 16), row = (int)(jr & 0xffffu);
     const h264e_frame_task_t &T = tasks[job];
     if (!T.active) return;
-    const h264e_chain_dev_t &C = chains[T.chain];
+    const ChainG C = chain_view(chains[T.chain]);
 
     if (row == G.nmby)
     {
@@ -76,14 +78,14 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
             if (threadIdx.x == 0)
             {
                 if (st == -1) *errflag = 1;
-                if (T.host_done) __hip_atomic_store(&T.host_done->done, -T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (T.host_done) __hip_atomic_store(&((GLOBAL_AS h264e_hostdone_t *)T.host_done)->done, -T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             return;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        finalize_frame(G, C, T, stepflags + 2*job);
+        finalize_frame(G, C, T, (GLOBAL_AS int *)stepflags + 2*job);
         if (T.host_done)
         {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
@@ -94,12 +96,13 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
             __syncthreads();
             if (threadIdx.x == 0)
             {
-                const h264e_frameout_t &F = C.fout[T.frame_slot];
-                T.host_done->nbytes = F.nbytes; T.host_done->all_skipped = F.all_skipped;
-                T.host_done->clusters_moved = F.clusters_moved; T.host_done->overflow = F.overflow;
+                const GLOBAL_AS h264e_frameout_t &F = C.fout[T.frame_slot];
+                GLOBAL_AS h264e_hostdone_t *hd = (GLOBAL_AS h264e_hostdone_t *)T.host_done;
+                hd->nbytes = F.nbytes; hd->all_skipped = F.all_skipped;
+                hd->clusters_moved = F.clusters_moved; hd->overflow = F.overflow;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                 /* system scope: the host reads these */
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&T.host_done->done, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&hd->done, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         return;
@@ -108,18 +111,18 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
     /* ---- macroblock row */
     row_begin(L, G, C, T, row);
     int seen = 0, seen_dep = 0;
-    const int dep_row = imin(row + 3, G.nmby - 1);
+    const int dep_row = imin(row + H264E_DEP_ROWS, G.nmby - 1);
     for (int x = 0; x < G.nmbx; x++)
     {
         /* consumer: relaxed polls, then ONE agent-scope acquire (invalidates this CU's L1) */
         const int need = row > 0 ? imin(x + 2, G.nmbx) : 0;
-        const int need_dep = T.dep_progress ? imin(x + 4, G.nmbx) : 0;     /* temporal wavefront: see rv_wait_rect */
+        const int need_dep = T.dep_progress ? imin(x + H264E_DEP_COLS, G.nmbx) : 0;     /* temporal wavefront: h264e_dev.h */
         int st = 0;
-        if (T.abort_word && __hip_atomic_load(T.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == T.launch_id) st = -2;
+        if (T.abort_word && uni(__hip_atomic_load((const GLOBAL_AS int *)T.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == T.launch_id) st = -2;
         if (!st && (seen < need || seen_dep < need_dep))
         {
             if (seen < need) st = poll_progress(C.progress + (row - 1), need, seen);
-            if (!st && seen_dep < need_dep) st = poll_progress(T.dep_progress + dep_row, need_dep, seen_dep);
+            if (!st && seen_dep < need_dep) st = poll_progress((const GLOBAL_AS int *)T.dep_progress + dep_row, need_dep, seen_dep);
             if (!st)
             {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -247,6 +250,7 @@ struct h264e_hip_pool
     h264e_frame_task_t *tasks_dev;       /* ring of TASK_RING task arrays */
     int *progress_all;
     int *errflag;
+    uint32_t *order;                     /* [nchains*(nmby+1)] (job << 16) | row in dispatch order */
     int *stepflags;                      /* [nchains][2]: {clusters_moved, overflow} of the last step, one read per step */
     /* streaming: per chain slot, host-mapped result buffers the finalizer workgroups fill while the launch runs */
     h264e_hostdone_t *host_done;         /* [nchains] */
@@ -299,7 +303,7 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
     if (p->host_mbrec) for (int c = 0; c < p->nchains; c++) host_free(p->host_mbrec[c]);
     host_free(p->host_done); host_free(p->abort_word);
     free(p->host_rbsp); free(p->host_mbrec); free(p->slot_launch);
-    dev_free(p->clip); dev_free(p->chains_dev); dev_free(p->tasks_dev); dev_free(p->progress_all); dev_free(p->errflag); dev_free(p->stepflags);
+    dev_free(p->clip); dev_free(p->chains_dev); dev_free(p->tasks_dev); dev_free(p->progress_all); dev_free(p->errflag); dev_free(p->stepflags); dev_free(p->order);
 #ifndef H264E_EMU
     if (p->stream)
     {
@@ -354,6 +358,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     bad |= dev_malloc((void **)&p->progress_all, sizeof(int)*(size_t)nchains*G.nmby);
     bad |= dev_malloc((void **)&p->errflag, sizeof(int));
     bad |= dev_malloc((void **)&p->stepflags, sizeof(int)*2*(size_t)nchains);
+    bad |= dev_malloc((void **)&p->order, sizeof(uint32_t)*(size_t)nchains*(G.nmby + 1));
     const size_t plane = (size_t)G.W*G.H*3/2;
     const uint32_t arena_cap = (uint32_t)((size_t)slots*((size_t)G.nmb*640 + 1024));
     p->host_rbsp_cap = (uint32_t)((size_t)G.nmb*640 + 1024);
@@ -401,6 +406,24 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     {
         h264e_hip_pool_destroy(p);
         FAIL("descriptor upload failed");
+    }
+    {
+        /* dispatch order: (job, row) sorted by the step at which the row can start when consecutive jobs are consecutive
+         * frames of one stream; every workgroup still only waits for workgroups that precede it in this order */
+        const int rows = G.nmby + 1, total = nchains*rows, maxkey = H264E_FRAME_LAG*(nchains - 1) + 2*(rows - 1);
+        uint32_t *ord = (uint32_t *)malloc(sizeof(uint32_t)*(size_t)total);
+        int n = 0;
+        if (!ord) { h264e_hip_pool_destroy(p); FAIL("out of host memory"); }
+        for (int key = 0; key <= maxkey; key++)
+            for (int job = 0; job < nchains; job++)
+            {
+                const int r2 = key - H264E_FRAME_LAG*job;
+                if (r2 < 0 || (r2 & 1) || (r2 >> 1) >= rows) continue;
+                ord[n++] = ((uint32_t)job << 16) | (uint32_t)(r2 >> 1);
+            }
+        const hipError_t e = (n == total) ? hipMemcpy(p->order, ord, sizeof(uint32_t)*(size_t)total, hipMemcpyHostToDevice) : hipErrorUnknown;
+        free(ord);
+        if (e != hipSuccess) { h264e_hip_pool_destroy(p); FAIL("dispatch order upload failed"); }
     }
 #endif
     *pool = p;
@@ -578,7 +601,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     {
         const h264e_frame_task_t &T = slot[c];
         if (!T.active) continue;
-        const h264e_chain_dev_t &C = p->chains_dev[T.chain];
+        const ChainG C = chain_view(p->chains_dev[T.chain]);
         for (int row = 0; row < G.nmby; row++)
         {
             RowLds *L = (RowLds *)calloc(1, sizeof(RowLds));
@@ -607,7 +630,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     const int pe = p->ev_pending;
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][0], p->stream));
     hipLaunchKernelGGL(h264e_mb_kernel, dim3((unsigned)(p->nchains*(G.nmby + 1))), dim3(64), 0, p->stream,
-                       G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, p->nchains, p->errflag, p->stepflags);
+                       G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, (const uint32_t *)p->order, p->errflag, p->stepflags);
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][1], p->stream));
     HIPCHK(hipGetLastError());
     if (p->profile)
