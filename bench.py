@@ -2,10 +2,13 @@
 """bench.py -- headline metric of BASELINE.json: 1080p macroblocks/sec, achieved HBM GB/s vs peak.
 
 A step = one pass of the encode path over one batch: a synthetic 1920x1080 I420 clip of 600 frames (synth_v1,
-generated in HBM before the timed region), IPPP GOP 30, QP 26, speed 0 (BASELINE.json configs[2]); the 20 GOPs run
-as parallel chains on the GPU.  The timed region covers everything after the input is resident: all kernel launches,
-read-back of the coded slices, host NAL assembly into the final Annex-B stream.
-With --gpus N (launched by torch.distributed.run) every rank encodes its own clip on its own GPU: GOPs/clips are
+generated in HBM before the timed region), IPPP GOP 30, QP 26, speed 0 (BASELINE.json configs[2]).  Consecutive frames
+run as a temporal wavefront inside one kernel launch (a P frame starts once its reference frame is a few macroblock
+rows ahead); finished frames are exported to host-mapped memory by the kernel and validated / NAL-assembled by the
+host while the launch is still running (DESIGN.md sections 4-5).  The timed region covers everything after the input
+is resident: all kernel launches incl. the relaunches after a mis-speculated mv_clusters state, the export of the
+coded slices, host NAL assembly into the final Annex-B stream.
+With --gpus N (launched by torch.distributed.run) every rank encodes its own clip on its own GPU: clips are
 independent, no data-path collective (weak scaling); torch.distributed only provides the barrier and the max-reduce.
 """
 import argparse
@@ -26,6 +29,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # algorithmic bytes per macroblock: input 384 B; P frames also read the co-located reference
 # (384 B); every frame writes 384 B of reconstruction
 BYTES_I, BYTES_P = 384 + 384, 768 + 384
+
+
+def _pmc_traffic():
+    """HBM bytes per h264e_mb_kernel launch from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in
+    separate runs of this same command; profiles/r01_pmc_traffic.json says how they were taken), or None"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(sample_frames=60):
@@ -107,8 +120,7 @@ def main():
     if rank == 0:
         total_mb = world * a.steps * frames * NMB
         value = total_mb / dt
-        gops = (frames + GOP - 1) // GOP
-        # per launch: one frame of every chain (the I frame of each GOP in launch 0, P frames afterwards)
+        # useful algorithmic bytes of the clip (frames that were encoded again after a mis-speculation count once)
         alg_bytes = a.steps * NMB * sum((BYTES_P if (f % GOP) else BYTES_I) for f in range(frames))
         achieved = alg_bytes / (mb_ms * 1e-3) / 1e9 if mb_ms > 0 else 0.0
         line = {
@@ -116,10 +128,10 @@ def main():
             "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "synthetic 1920x1080 YUV420 %d frames IPPP GOP %d QP %d on 1xMI355X per rank (BASELINE configs[2])" % (frames, GOP, QP),
-                       "frames_per_step": frames, "gop_chains": gops, "fps": world * a.steps * frames / dt,
-                       "coded_bytes_per_step": len(out), "reencoded_gops": st.reencoded_gops},
+                       "frames_per_step": frames, "frames_in_flight": st.chains, "fps": world * a.steps * frames / dt,
+                       "coded_bytes_per_step": len(out), "relaunches_per_step": st.reencoded_gops},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "h264e_mb_kernel", "launches": launches, "avg_launch_ms": mb_ms / max(launches, 1),
+                         "traffic": _pmc_traffic(), "kernel": "h264e_mb_kernel", "launches": launches, "avg_launch_ms": mb_ms / max(launches, 1),
                          "bytes_per_launch": alg_bytes / max(launches, 1), "splice_kernel_ms_total": splice_ms},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -7,11 +7,14 @@
  * i.e. everything the reference reaches through its function table h264e_* (h264-lab.h:3274-3364).
  * Plain pointers and sizes only; no C++ or torch types.
  *
- * A POOL holds `nchains` independent encoder chains of one picture geometry on one GPU.  A chain is a
- * sequential stream of frames (reference / reconstruction ping-pong); independent GOPs are run as
- * separate chains in the same kernel launch.  One h264e_hip_submit() call encodes
- * one frame of every active chain: the macroblock kernel (one wavefront per macroblock row) followed by
- * the slice splice kernel.  Calls are asynchronous on the pool's stream until h264e_hip_sync().
+ * A POOL holds `nchains` slots of one picture geometry on one GPU (picture, row bit buffers, per-macroblock
+ * records, result buffers).  One h264e_hip_submit() call launches the macroblock kernel once for up to nchains
+ * jobs (one wavefront per macroblock row plus one finalizer wavefront per job that splices the slice):
+ *  - plain mode: job c is the next frame of independent chain c (reference / reconstruction ping-pong);
+ *  - stream mode: the jobs are consecutive frames of ONE stream, run as a temporal wavefront (a P frame starts
+ *    while its reference frame is a few macroblock rows ahead); finished frames are
+ *    exported to host-mapped memory and can be consumed with h264e_hip_stream_* while the launch runs.
+ * Calls are asynchronous on the pool's stream until h264e_hip_sync().
  */
 #ifndef H264E_HIP_H
 #define H264E_HIP_H

@@ -107,14 +107,15 @@ void H264E_set_device(int device);
 /* Last device-side error text (empty when none). */
 const char *H264E_last_error(void);
 
-/* Whole-clip encode with independent GOPs run as parallel chains on one GPU:
- * bit-identical to feeding the frames one by one to H264E_encode.  Constant QP only. */
+/* Whole-clip streaming encode: consecutive frames run as a temporal wavefront inside one
+ * kernel launch, finished frames are validated and NAL-assembled by the host while the launch runs (DESIGN.md
+ * sections 4-5).  Bit-identical to feeding the frames one by one to H264E_encode.  Constant QP only. */
 typedef struct
 {
     int width, height, gop, qp, speed;
     int vbv_size_bytes;                     /* SPS level only */
     int device;
-    int max_chains;                         /* GOP chains in flight (0 = all GOPs of the clip) */
+    int max_chains;                         /* frames in flight per launch (0 = default 48) */
     int first_idr_pic_id_state;             /* enc->next_idr_pic_id before the first frame (0 for a fresh stream) */
     int32_t mv_clusters_in[2];              /* enc->mv_clusters before the first frame (0,0 for a fresh stream) */
 } H264E_clip_param_t;
@@ -122,9 +123,9 @@ typedef struct
 typedef struct
 {
     double upload_ms, encode_ms, readback_ms, assemble_ms;      /* host wall clock of the phases */
-    double mb_kernel_ms, splice_kernel_ms;                      /* HIP-event time inside the kernels (when profiled) */
+    double mb_kernel_ms, splice_kernel_ms;                      /* HIP-event time inside the kernel launches (when profiled); the splice runs inside the macroblock kernel: second value ~0 */
     int kernel_launches;
-    int chains, rounds, reencoded_gops;
+    int chains, rounds, reencoded_gops;                         /* frames in flight per launch, launches, relaunches after a mis-speculated mv_clusters state */
     int32_t mv_clusters_out[2];
     int next_idr_pic_id_state;
 } H264E_clip_stats_t;
