@@ -794,8 +794,31 @@ DEV void wave_recon(uint8_t *out, int os, const uint8_t *pred, const qblk_t *q, 
  * index order; nctx = left + top nnz context (NNZ_NA = 64 per unavailable side, 17+17 = chroma DC table).
  * Works from the 16-bit mask of non-zero positions, so no per-lane arrays are needed.  Returns TotalCoeff.
  */
-DEV int cavlc_block(BitW &b, const int16_t *base, int first, int maxn, int nctx)
+/* the CAVLC code tables of tables.h in LDS, one 16-bit entry = length | code << 8 (one ds_read per lookup) */
+struct CavlcTab
 {
+    uint16_t coeff_token[5*17*4];
+    uint16_t total_zeros[15*16];
+    uint16_t total_zeros_cdc[3*4];
+    uint16_t run_before[7*15];
+    uint16_t pad;
+};
+/* one lane per entry; call from every lane of the wave */
+DEV void cavlc_tab_load(CavlcTab &t)
+{
+    WAVE_FOR(l)
+    {
+        for (int k = l; k < 5*17*4; k += 64) { const uint8_t *e = &k_coeff_token[0][0][0][0] + 2*k; t.coeff_token[k] = (uint16_t)(e[0] | (e[1] << 8)); }
+        for (int k = l; k < 15*16; k += 64) { const uint8_t *e = &k_total_zeros[0][0][0] + 2*k; t.total_zeros[k] = (uint16_t)(e[0] | (e[1] << 8)); }
+        for (int k = l; k < 3*4; k += 64) { const uint8_t *e = &k_total_zeros_cdc[0][0][0] + 2*k; t.total_zeros_cdc[k] = (uint16_t)(e[0] | (e[1] << 8)); }
+        for (int k = l; k < 7*15; k += 64) { const uint8_t *e = &k_run_before[0][0][0] + 2*k; t.run_before[k] = (uint16_t)(e[0] | (e[1] << 8)); }
+    }
+}
+DEV void bw_put_tab(BitW &b, uint16_t e) { bw_put(b, (int)(e & 255), (uint32_t)(e >> 8)); }
+
+DEV int cavlc_block(BitW &b, const CavlcTab &ct, const int16_t *base, int first, int maxn, int nctx)
+{
+    first = uni(first); maxn = uni(maxn); nctx = uni(nctx);
     uint32_t mask = 0;
     {
         const uint32_t *w = (const uint32_t *)base;
@@ -808,7 +831,7 @@ DEV int cavlc_block(BitW &b, const int16_t *base, int first, int maxn, int nctx)
                 if (v & 0xffffu) mask |= 1u << (2*k);
                 if (v >> 16) mask |= 2u << (2*k);
             }
-        mask = (mask >> first) & ((1u << maxn) - 1);
+        mask = (uint32_t)uni((int)((mask >> first) & ((1u << maxn) - 1)));     /* scalar from here on */
     }
 #ifdef H264E_EMU
     const int total = __builtin_popcount(mask);
@@ -823,7 +846,7 @@ DEV int cavlc_block(BitW &b, const int16_t *base, int first, int maxn, int nctx)
         while (m && t1 < 3)
         {
             const int p = 31 - clz32(m);
-            const int c = base[first + p];
+            const int c = uni(base[first + p]);
             if (c != 1 && c != -1) break;
             t1sign = (t1sign << 1) | (uint32_t)(c < 0);
             t1++;
@@ -833,7 +856,7 @@ DEV int cavlc_block(BitW &b, const int16_t *base, int first, int maxn, int nctx)
     if (nctx <= 34) nctx = (nctx + 1) >> 1;
     nctx &= 31;
     const int tab = nctx < 2 ? 0 : nctx < 4 ? 1 : nctx < 8 ? 2 : nctx < 17 ? 3 : 4;
-    bw_put(b, k_coeff_token[tab][total][t1][0], k_coeff_token[tab][total][t1][1]);
+    bw_put_tab(b, (uint16_t)uni(ct.coeff_token[(tab*17 + total)*4 + t1]));
     if (!total) return 0;
     if (t1) bw_put(b, t1, t1sign);
     uint32_t m = mask;
@@ -843,7 +866,7 @@ DEV int cavlc_block(BitW &b, const int16_t *base, int first, int maxn, int nctx)
     {
         const int p = 31 - clz32(m);
         m &= ~(1u << p);
-        const int lv = base[first + p], a = iabs(lv);
+        const int lv = uni(base[first + p]), a = iabs(lv);
         int code = 2*a - 2 + (lv < 0), prefix, nsuf, suf;
         if (firstlev && t1 < 3) code -= 2;
         firstlev = 0;
@@ -866,8 +889,8 @@ DEV int cavlc_block(BitW &b, const int16_t *base, int first, int maxn, int nctx)
     {
         const int top = 31 - clz32(mask);
         int zeros = top + 1 - total;
-        if (maxn == 4) bw_put(b, k_total_zeros_cdc[total - 1][zeros][0], k_total_zeros_cdc[total - 1][zeros][1]);
-        else           bw_put(b, k_total_zeros[total - 1][zeros][0], k_total_zeros[total - 1][zeros][1]);
+        if (maxn == 4) bw_put_tab(b, (uint16_t)uni(ct.total_zeros_cdc[(total - 1)*4 + zeros]));
+        else           bw_put_tab(b, (uint16_t)uni(ct.total_zeros[(total - 1)*16 + zeros]));
         uint32_t r = mask & ~(1u << top);
         int prev = top;
         while (r && zeros > 0)
@@ -875,7 +898,7 @@ DEV int cavlc_block(BitW &b, const int16_t *base, int first, int maxn, int nctx)
             const int p = 31 - clz32(r);
             r &= ~(1u << p);
             const int run = prev - p - 1, zl = zeros > 7 ? 7 : zeros;
-            bw_put(b, k_run_before[zl - 1][run][0], k_run_before[zl - 1][run][1]);
+            bw_put_tab(b, (uint16_t)uni(ct.run_before[(zl - 1)*15 + run]));
             zeros -= run;
             prev = p;
         }

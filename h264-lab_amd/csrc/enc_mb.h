@@ -41,6 +41,7 @@ struct RowLds
     int8_t i4_mode[16];
     alignas(4) uint8_t bs[32];
     I4Scratch i4s;
+    CavlcTab cavlc;
     uint8_t nzctx[12];
     uint16_t qdat[2][42];                           /* this frame's quantizer tables, copied from the task */
     alignas(16) uint8_t win[WIN_W*WIN_STRIDE + 16];  /* reference luma window around the current macroblock */
@@ -330,8 +331,9 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
         }, s8);
         wave_sync();
         int best = -1;
-        mv32 vbest = mv;
-#define TRY(i, vv) { const int cst = s8[i] + mv_cost(m, vv, mv_pred); if (cst < min_sad) { min_sad = cst; vbest = vv; best = i; } }
+        mv32 vbest = (mv32)uni(mv);
+        /* uni(): keeps the scalar bookkeeping below from being merged with the same expressions inside the lane code above */
+#define TRY(i, vv) { const mv32 vu = (mv32)uni(vv); const int cst = s8[i] + mv_cost(m, vu, mv_pred); if (cst < min_sad) { min_sad = cst; vbest = vu; best = i; } }
         TRY(0, v02) TRY(1, v01) TRY(2, v20) TRY(3, v10) TRY(4, v11) TRY(5, v22) TRY(6, v12)
 #undef TRY
         const uint8_t *src = best < 0 ? L.p00 : best == 0 ? L.p02 : best == 1 ? L.skip_tmp[0] : best == 2 ? L.p20 : best == 3 ? L.skip_tmp[1] :
@@ -503,6 +505,7 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
         if (!(t == 0 ? prefer[0] : t == 1 ? prefer[1] : t == 2 ? prefer[2] : prefer[3])) continue;
         for (;;)
         {
+            PTIC();
             rect_t range;
             mv32 mvabs = mb_abs(m, mv_best);
             set_range(mvabs, range, lim, m.y*64 + py*4);
@@ -514,6 +517,7 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
                 sad_best = wave_sad_ref(R, px + (mvx(mvabs) >> 2), py + (mvy(mvabs) >> 2), L.inp + 16*py + px, w, h)
                          + mv_cost(m, mvabs, mb_abs(m, mvp));
             }
+            PTOC(L, 27);
             part_sad += diamond(L, m, px, py, mvabs, range, mb_abs(m, mvp), sad_best, w, h, L.test + 16*py + px);
             /* the partition costs only add up: once they reach the best cost so far this partitioning cannot win (H:5500 is a
              * strict "<"), and nothing else of it is observable -- the predictor context is restored below */
@@ -784,7 +788,7 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
         cbp = cbpl + (cbpc << 4);
         if (!i16) bw_ue(b, k_cbp2code[m.type < 5][cbp]);
         if (cbp || i16) bw_se(b, 0);                    /* mb_qp_delta: QP is constant within a frame (no MB-level rate control) */
-        if (i16) nz[4] = (uint8_t)cavlc_block(b, L.lev_dcy, 0, 16, nz[3] + nz[5]);
+        if (i16) nz[4] = (uint8_t)cavlc_block(b, L.cavlc, L.lev_dcy, 0, 16, nz[3] + nz[5]);
         if (cbpl)
         {
             for (int i = 0; i < 16; i++)
@@ -792,7 +796,7 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
                 const int j = SCAN8(i), k = 4 + (j & 3) - (j >> 2);
                 if (cbp & (1 << (i >> 2)))
                 {
-                    nz[k] = (uint8_t)cavlc_block(b, L.qy[j].qv, i16, 16 - i16, nz[k - 1] + nz[k + 1]);
+                    nz[k] = (uint8_t)cavlc_block(b, L.cavlc, L.qy[j].qv, i16, 16 - i16, nz[k - 1] + nz[k + 1]);
                     if (nz[k]) L.df_nzflag |= 1u << (5 + (j & 3) + 5*(j >> 2));
                 } else
                     nz[k] = 0;
@@ -805,8 +809,8 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
         }
         if (cbpc)
         {
-            cavlc_block(b, L.lev_dcu, 0, 4, 17 + 17);
-            cavlc_block(b, L.lev_dcv, 0, 4, 17 + 17);
+            cavlc_block(b, L.cavlc, L.lev_dcu, 0, 4, 17 + 17);
+            cavlc_block(b, L.cavlc, L.lev_dcv, 0, 4, 17 + 17);
             if (cbpc > 1)
                 for (int c = 0; c < 2; c++)
                 {
@@ -822,7 +826,7 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
                     for (int i = 0; i < 4; i++)
                     {
                         const int k = 2 + (i & 1) - (i >> 1);
-                        nzc[k] = (uint8_t)cavlc_block(b, q[i].qv, 1, 15, nzc[k - 1] + nzc[k + 1]);
+                        nzc[k] = (uint8_t)cavlc_block(b, L.cavlc, q[i].qv, 1, 15, nzc[k - 1] + nzc[k + 1]);
                     }
                     for (int i = 0; i < 2; i++)
                     {

@@ -60,6 +60,7 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
         for (int k = l; k < 84; k += 64) L.qdat[k/42][k%42] = T.qdat[k/42][k%42];
         for (int k = l; k < 144; k += 64) L.i4s.lut[k] = k_i4_lut[k/16][k%16];
     }
+    cavlc_tab_load(L.cavlc);
     for (int i = 0; i < 32; i++) L.prof[i] = 0;
     L.prof_last = 0;
     wave_sync();
@@ -124,6 +125,7 @@ DEV void load_input(RowLds &L, const h264e_geom_t &G, const h264e_frame_task_t &
 DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, int row, int x)
 {
     MbCtx m;
+    PTIC();
     m.G = &G; m.T = &T;
     for (int c = 0; c < 3; c++)
     {
@@ -295,6 +297,7 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
     wave_sync();
     STAMP(L, 12);
     L.prof[20 + (m.type < 0 ? 0 : m.type < 5 ? 1 : 2)]++;
+    PTOC(L, 24 + (m.type < 0 ? 0 : m.type < 5 ? 1 : 2));
 }
 
 DEV void row_end(RowLds &L, const h264e_geom_t &G, const ChainG &C, int row)

@@ -725,7 +725,7 @@ int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nfram
     /* ring of picture / result slots = frames per launch + 1.  Not bounded by residency: workgroups only wait for lower
      * block indices, so a launch larger than the GPU simply streams through it in order. */
     (void)nmby; (void)cap;
-    c->ring = par->max_chains > 0 ? par->max_chains + 1 : 49;
+    c->ring = par->max_chains > 0 ? par->max_chains + 1 : 97;
     if (getenv("H264E_RING")) c->ring = atoi(getenv("H264E_RING"));       /* experiments */
     c->ring = imax(2, imin(c->ring, nframes + 1));
     if (h264e_hip_pool_create(&c->pool, par->device, par->width, par->height, c->ring, nframes, 1))

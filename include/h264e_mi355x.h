@@ -115,7 +115,7 @@ typedef struct
     int width, height, gop, qp, speed;
     int vbv_size_bytes;                     /* SPS level only */
     int device;
-    int max_chains;                         /* frames in flight per launch (0 = default 48) */
+    int max_chains;                         /* frames in flight per launch (0 = default 96) */
     int first_idr_pic_id_state;             /* enc->next_idr_pic_id before the first frame (0 for a fresh stream) */
     int32_t mv_clusters_in[2];              /* enc->mv_clusters before the first frame (0,0 for a fresh stream) */
 } H264E_clip_param_t;

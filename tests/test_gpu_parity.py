@@ -107,6 +107,32 @@ def test_1080p_full_size_properties(P):
     assert got == a[: sum(fa[:6])]
 
 
+def test_1080p_streaming_through_misspeculation(P):
+    """40 frames of the bench clip: the rounded mv_clusters candidates change at frames 17, 21 and 33, so the streaming
+    encoder aborts and relaunches three times; the stream must still equal the oracle's byte for byte"""
+    w, h, n, gop = 1920, 1080, 40, 30
+    ce = P.ClipEncoder(w, h, n, gop=gop, qp=26)
+    ce.generate_synth()
+    out, fs, st = ce.encode()
+    ce.close()
+    assert st.reencoded_gops >= 1, "the clip no longer exercises the relaunch path"
+    c = oracle_lib.synth_c(w, h, n)
+    want, sizes = oracle_lib.encode_clip(c, w, h, gop=gop, qp=26)
+    assert fs == sizes and out == want
+
+
+@pytest.mark.parametrize("w,h,n", [(3840, 2160, 3), (7680, 4320, 2)])
+def test_4k_8k_match_oracle(P, w, h, n):
+    """BASELINE configs[3]/[4] geometry (32 400 / 129 600 macroblocks per frame, 8K is cropped): I + P frames"""
+    ce = P.ClipEncoder(w, h, n, gop=30, qp=26)
+    ce.generate_synth()
+    out, fs, _ = ce.encode()
+    ce.close()
+    c = oracle_lib.synth_c(w, h, n)
+    want, sizes = oracle_lib.encode_clip(c, w, h, gop=30, qp=26)
+    assert fs == sizes and out == want
+
+
 def test_error_codes(P):
     import ctypes as C
     L = P.load()
