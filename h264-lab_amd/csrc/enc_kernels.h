@@ -555,6 +555,9 @@ DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_
         const int hl = (avail & AV_L) != 0, ht = (avail & AV_T) != 0;
         dc = (hl && ht) ? (sl + st + 4) >> 3 : hl ? (sl + 2) >> 2 : ht ? (st + 2) >> 2 : 128;
     }
+    const int have_t = (avail & AV_T) != 0, have_l = (avail & AV_L) != 0, have_all = (avail & (AV_T | AV_L | AV_TL)) == (AV_T | AV_L | AV_TL);
+    int best = 0, best_sad = 0;
+#ifdef H264E_EMU
     WAVE_FOR(l)
     {
         const int k = l >> 2, y = l & 3;
@@ -567,9 +570,6 @@ DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_
         }
     }
     wave_sync();
-    const int have_t = (avail & AV_T) != 0, have_l = (avail & AV_L) != 0, have_all = (avail & (AV_T | AV_L | AV_TL)) == (AV_T | AV_L | AV_TL);
-    int best = 0, best_sad = 0;
-#pragma unroll
     for (int k = 0; k < 9; k++)
     {
         const int m = k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 3 : k == 3 ? 7 : k == 4 ? 1 : k == 5 ? 8 : k == 6 ? 4 : k == 7 ? 6 : 5;
@@ -582,6 +582,33 @@ DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_
         if (l < 4) lds32_store(pred + 16*l, S.rows[4*best + l]);
     }
     wave_sync();
+#else
+    {
+        /* same computation with the rows and their SADs kept in registers: lane 4k + y holds row y of mode slot k, the four
+         * row SADs of a slot are added inside the quad (DPP) and read with v_readlane -- no LDS round trips for the choice */
+        const int l = (int)threadIdx.x, k = l >> 2, y = l & 3;
+        uint32_t row = 0;
+        int qs = 0;
+        if (k < 9)
+        {
+            const int m = k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 3 : k == 3 ? 7 : k == 4 ? 1 : k == 5 ? 8 : k == 6 ? 4 : k == 7 ? 6 : 5;
+            row = i4_pred_row(m, y, S.edge, dc, S.lut);
+            qs = (int)sad4_u8(lds32(in + 16*y), row, 0);
+        }
+        qs += __builtin_amdgcn_update_dpp(0, qs, 0xB1, 0xf, 0xf, true);      /* quad_perm [1,0,3,2] */
+        qs += __builtin_amdgcn_update_dpp(0, qs, 0x4E, 0xf, 0xf, true);      /* quad_perm [2,3,0,1] */
+#pragma unroll
+        for (int kk = 0; kk < 9; kk++)
+        {
+            const int m = kk == 0 ? 2 : kk == 1 ? 0 : kk == 2 ? 3 : kk == 3 ? 7 : kk == 4 ? 1 : kk == 5 ? 8 : kk == 6 ? 4 : kk == 7 ? 6 : 5;
+            const int ok = kk == 0 ? 1 : kk <= 3 ? have_t : kk <= 5 ? have_l : have_all;
+            const int sad = __builtin_amdgcn_readlane(qs, 4*kk) + (m != mpred ? penalty : 0);
+            if (ok && (kk == 0 || sad < best_sad)) { best = kk; best_sad = sad; }
+        }
+        if (k == best) lds32_store(pred + 16*y, row);
+        wave_sync();
+    }
+#endif
     const int bm = best == 0 ? 2 : best == 1 ? 0 : best == 2 ? 3 : best == 3 ? 7 : best == 4 ? 1 : best == 5 ? 8 : best == 6 ? 4 : best == 7 ? 6 : 5;
     return bm + (best_sad << 4);
 }
@@ -820,10 +847,10 @@ DEV int cavlc_block(BitW &b, const CavlcTab &ct, const int16_t *base, int first,
 {
     first = uni(first); maxn = uni(maxn); nctx = uni(nctx);
     uint32_t mask = 0;
+#ifdef H264E_EMU
     {
         const uint32_t *w = (const uint32_t *)base;
         const int nw = (first + maxn + 1) >> 1;
-#pragma unroll
         for (int k = 0; k < 8; k++)
             if (k < nw)
             {
@@ -831,8 +858,16 @@ DEV int cavlc_block(BitW &b, const CavlcTab &ct, const int16_t *base, int first,
                 if (v & 0xffffu) mask |= 1u << (2*k);
                 if (v >> 16) mask |= 2u << (2*k);
             }
-        mask = (uint32_t)uni((int)((mask >> first) & ((1u << maxn) - 1)));     /* scalar from here on */
+        mask = (mask >> first) & ((1u << maxn) - 1);
     }
+#define COEF(p) ((int)base[first + (p)])
+#else
+    /* one LDS read for the whole block: lane p holds coefficient p; the scalar code below picks coefficients with
+     * v_readlane instead of one LDS round trip each */
+    const int cv = (int)threadIdx.x < maxn ? (int)base[first + (int)threadIdx.x] : 0;
+    mask = (uint32_t)__ballot(cv != 0);
+#define COEF(p) __builtin_amdgcn_readlane(cv, (p))
+#endif
 #ifdef H264E_EMU
     const int total = __builtin_popcount(mask);
 #else
@@ -846,7 +881,7 @@ DEV int cavlc_block(BitW &b, const CavlcTab &ct, const int16_t *base, int first,
         while (m && t1 < 3)
         {
             const int p = 31 - clz32(m);
-            const int c = uni(base[first + p]);
+            const int c = COEF(p);
             if (c != 1 && c != -1) break;
             t1sign = (t1sign << 1) | (uint32_t)(c < 0);
             t1++;
@@ -866,7 +901,7 @@ DEV int cavlc_block(BitW &b, const CavlcTab &ct, const int16_t *base, int first,
     {
         const int p = 31 - clz32(m);
         m &= ~(1u << p);
-        const int lv = uni(base[first + p]), a = iabs(lv);
+        const int lv = COEF(p), a = iabs(lv);
         int code = 2*a - 2 + (lv < 0), prefix, nsuf, suf;
         if (firstlev && t1 < 3) code -= 2;
         firstlev = 0;
@@ -903,6 +938,7 @@ DEV int cavlc_block(BitW &b, const CavlcTab &ct, const int16_t *base, int first,
             prev = p;
         }
     }
+#undef COEF
     return total;
 }
 

@@ -223,10 +223,11 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
                             const int r = l >> (g >> 1), c4 = l & (g - 1);
                             const uint32_t in4 = lds32(b + 16*r + 4*c4);
                             const lu8 *p = base + r*WIN_STRIDE + 4*c4;
-                            if (want & 1) sv[0] = (int)sad4_u8(lds32u(p + 1), in4, 0);
-                            if (want & 2) sv[1] = (int)sad4_u8(lds32u(p - 1), in4, 0);
-                            if (want & 4) sv[2] = (int)sad4_u8(lds32u(p + WIN_STRIDE), in4, 0);
-                            if (want & 8) sv[3] = (int)sad4_u8(lds32u(p - WIN_STRIDE), in4, 0);
+                            /* all four neighbours lie inside the window: issue the loads together (one LDS wait instead of four);
+                             * sums of directions that are not wanted are simply not looked at */
+                            const uint32_t a0 = lds32u(p + 1), a1 = lds32u(p - 1), a2 = lds32u(p + WIN_STRIDE), a3 = lds32u(p - WIN_STRIDE);
+                            sv[0] = (int)sad4_u8(a0, in4, 0); sv[1] = (int)sad4_u8(a1, in4, 0);
+                            sv[2] = (int)sad4_u8(a2, in4, 0); sv[3] = (int)sad4_u8(a3, in4, 0);
                         }, s4);
                     } else
                     {

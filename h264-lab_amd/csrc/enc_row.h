@@ -17,6 +17,7 @@
 struct ChainG
 {
     GLOBAL_AS h264e_mbbottom_t *bottom;
+    GLOBAL_AS h264e_mbpend_t *pend;
     GLOBAL_AS int *progress;
     GLOBAL_AS uint32_t *rowbits;
     GLOBAL_AS h264e_rowmeta_t *rowmeta;
@@ -30,7 +31,7 @@ struct ChainG
 DEV ChainG chain_view(const h264e_chain_dev_t &C)
 {
     ChainG g;
-    g.bottom = (GLOBAL_AS h264e_mbbottom_t *)C.bottom; g.progress = (GLOBAL_AS int *)C.progress;
+    g.bottom = (GLOBAL_AS h264e_mbbottom_t *)C.bottom; g.pend = (GLOBAL_AS h264e_mbpend_t *)C.pend; g.progress = (GLOBAL_AS int *)C.progress;
     g.rowbits = (GLOBAL_AS uint32_t *)C.rowbits; g.rowmeta = (GLOBAL_AS h264e_rowmeta_t *)C.rowmeta;
     g.mbrec = (GLOBAL_AS h264e_mbrec_t *)C.mbrec; g.arena = (GLOBAL_AS uint8_t *)C.arena; g.arena_cap = C.arena_cap;
     g.cursor = (GLOBAL_AS uint32_t *)C.cursor; g.fout = (GLOBAL_AS h264e_frameout_t *)C.fout; g.prof = C.prof;
@@ -122,6 +123,20 @@ DEV void load_input(RowLds &L, const h264e_geom_t &G, const h264e_frame_task_t &
     wave_sync();
 }
 
+/* What macroblock (x, row) needs that does not depend on the row above: its input samples and, for P slices, the
+ * reference window (the caller has waited for the temporal dependency).  Issued BEFORE the wait for the row above, so
+ * the HBM latency of these loads overlaps with that wait. */
+DEV void row_prefetch(RowLds &L, const h264e_geom_t &G, const h264e_frame_task_t &T, int row, int x)
+{
+    load_input(L, G, T, x, row);
+    if (T.slice_type == 0)
+    {
+        Plane P;
+        P.p = (const gu8 *)T.ref[0]; P.w = G.W; P.h = G.H; P.stride = G.W;
+        wave_load_window(L.win, P, x*16 - WIN_M, row*16 - WIN_M);
+    }
+}
+
 DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, int row, int x)
 {
     MbCtx m;
@@ -144,14 +159,9 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
     GLOBAL_AS h264e_mbbottom_t *rowrec = C.bottom + (size_t)row*G.nmbx;
     STAMP(L, 0);
     load_top(L, G, rowrec - G.nmbx, x, row > 0);
-    load_input(L, G, T, x, row);
+    /* the input macroblock and the reference window are already in LDS (row_prefetch) */
     m.rv.dep = (const GLOBAL_AS int *)T.dep_progress; m.rv.nmbx = G.nmbx; m.rv.nmby = G.nmby;
-    m.rv.P = m.ref[0]; m.rv.win = (const lu8 *)L.win; m.rv.has_win = 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
-    if (T.slice_type == 0)
-    {
-        wave_load_window(L.win, m.ref[0], m.rv.wx0, m.rv.wy0);
-        m.rv.has_win = 1;
-    }
+    m.rv.P = m.ref[0]; m.rv.win = (const lu8 *)L.win; m.rv.has_win = T.slice_type == 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
     STAMP(L, 1);
 
     BitW bw = L.bw;
@@ -205,10 +215,13 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
     }
     wave_sync();
 
-    /* deblock on the LDS tiles: left strips from LDS (previous macroblock), top strips from HBM (row above) */
+    /* deblock on the LDS tiles: left strips from LDS (previous macroblock), top strips from the pending lines of the
+     * row above (h264e_mbpend_t) */
     const int W = G.W, Wc = G.W >> 1;
     gu8 *dy = m.dec[0] + (size_t)(row*16)*W + x*16;
     gu8 *du = m.dec[1] + (size_t)(row*8)*Wc + x*8, *dv = m.dec[2] + (size_t)(row*8)*Wc + x*8;
+    GLOBAL_AS h264e_mbpend_t *pend_row = C.pend + (size_t)row*G.nmbx;
+    const bool direct = T.no_deblock || row == G.nmby - 1;      /* nothing below will filter the bottom lines: they are final now */
     if (!T.no_deblock)
     {
         df_strength(L, m, L.top_type);
@@ -224,51 +237,65 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
             {
                 int r = (l - 32) >> 2, c = l & 3;
                 uint32_t v = 0;
-                if (row > 0) v = gload32(dy - (size_t)(4 - r)*W + 4*c);
+                if (row > 0) v = gload32((const gu8 *)(pend_row - G.nmbx)[x].y + 16*r + 4*c);
                 lds32_store(L.ytile + r*YT_STRIDE + 4 + 4*c, v);
             } else if (l < 56)
             {
                 int pl = (l >> 2) & 1, r = (l >> 1) & 1, c = l & 1;
-                const gu8 *s = (pl ? dv : du) - (size_t)(2 - r)*Wc + 4*c;
-                uint8_t *t = L.ctile[pl] + r*CT_STRIDE + 2 + 4*c;
-                for (int k = 0; k < 4; k++) t[k] = row > 0 ? s[k] : 0;
+                uint32_t v = 0;
+                if (row > 0) v = gload32((const gu8 *)(pend_row - G.nmbx)[x].c[pl] + 8*r + 4*c);
+                memcpy(L.ctile[pl] + r*CT_STRIDE + 2 + 4*c, &v, 4);
             }
         }
         wave_sync();
         wave_deblock(L.ytile, L.ctile[0], L.ctile[1], L.bs, T.qp, L.left_qp, L.top_qp);
     }
-    /* write the macroblock and the neighbour samples the filter changed (3 luma / 1 chroma sample deep) */
+    /* write the macroblock: final lines into the picture, the bottom lines into the pending record */
     WAVE_FOR(l)
     {
         int r = l >> 2, c = l & 3;
         uint32_t v = lds32(ty + YT_STRIDE*r + 4*c);
-        gstore32(dy + (size_t)r*W + 4*c, v);
+        if (r < 12 || direct) gstore32(dy + (size_t)r*W + 4*c, v);
+        else gstore32((gu8 *)pend_row[x].y + 16*(r - 12) + 4*c, v);
         if (l < 32)
         {
             int pl = l >> 4, rr = (l >> 1) & 7, g = l & 1;
             uint32_t u = lds32((pl ? tc1 : tc0) + CT_STRIDE*rr + 4*g);
-            gstore32((pl ? dv : du) + (size_t)rr*Wc + 4*g, u);
+            if (rr < 6 || direct) gstore32((pl ? dv : du) + (size_t)rr*Wc + 4*g, u);
+            else gstore32((gu8 *)pend_row[x].c[pl] + 8*(rr - 6) + 4*g, u);
         }
     }
     if (!T.no_deblock)
     {
+        /* the neighbour samples the filter changed: 3 luma / 1 chroma columns of the left macroblock (picture, or its pending
+         * record for the bottom lines), and the 4 luma / 2 chroma lines above, which are final now */
         WAVE_FOR(l)
         {
             if (l < 16)
             {
-                if (x > 0) { uint32_t v = lds32(L.ytile + (4 + l)*YT_STRIDE); gstore32(dy + (size_t)l*W - 4, v); }
-            } else if (l < 28)
+                if (x > 0)
+                {
+                    uint32_t v = lds32(L.ytile + (4 + l)*YT_STRIDE);
+                    if (l < 12 || direct) gstore32(dy + (size_t)l*W - 4, v);
+                    else gstore32((gu8 *)pend_row[x - 1].y + 16*(l - 12) + 12, v);
+                }
+            } else if (l < 32)
             {
-                int r = 1 + (l - 16)/4, c = l & 3;                          /* rows -3..-1 of the tile = rows 1..3 */
+                int r = (l - 16) >> 2, c = l & 3;                           /* tile rows 0..3 = picture rows -4..-1 */
                 if (row > 0) { uint32_t v = lds32(L.ytile + r*YT_STRIDE + 4 + 4*c); gstore32(dy - (size_t)(4 - r)*W + 4*c, v); }
-            } else if (l < 44)
-            {
-                int pl = (l - 28) >> 3, i = (l - 28) & 7;
-                if (x > 0) (pl ? dv : du)[(size_t)i*Wc - 1] = L.ctile[pl][(2 + i)*CT_STRIDE + 1];
             } else if (l < 48)
             {
-                int pl = (l - 44) >> 1, c = l & 1;
-                if (row > 0) { uint32_t v; memcpy(&v, L.ctile[pl] + CT_STRIDE + 2 + 4*c, 4); gstore32((pl ? dv : du) - Wc + 4*c, v); }
+                int pl = (l - 32) >> 3, i = (l - 32) & 7;
+                if (x > 0)
+                {
+                    const uint8_t b1 = L.ctile[pl][(2 + i)*CT_STRIDE + 1];
+                    if (i < 6 || direct) (pl ? dv : du)[(size_t)i*Wc - 1] = b1;
+                    else ((gu8 *)pend_row[x - 1].c[pl])[8*(i - 6) + 7] = b1;
+                }
+            } else if (l < 56)
+            {
+                int pl = (l - 48) >> 2, r = (l >> 1) & 1, c = l & 1;       /* tile rows 0..1 = picture rows -2..-1 */
+                if (row > 0) { uint32_t v; memcpy(&v, L.ctile[pl] + r*CT_STRIDE + 2 + 4*c, 4); gstore32((pl ? dv : du) - (size_t)(2 - r)*Wc + 4*c, v); }
             }
         }
     }
@@ -296,7 +323,7 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
     L.left_qp = T.qp;
     wave_sync();
     STAMP(L, 12);
-    L.prof[20 + (m.type < 0 ? 0 : m.type < 5 ? 1 : 2)]++;
+    PCOUNT(L, 20 + (m.type < 0 ? 0 : m.type < 5 ? 1 : 2));
     PTOC(L, 24 + (m.type < 0 ? 0 : m.type < 5 ? 1 : 2));
 }
 

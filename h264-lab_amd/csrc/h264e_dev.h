@@ -6,6 +6,7 @@
  *               out-of-picture reference reads clamp coordinates, which equals the reference's
  *               replicated borders (h264-lab.h:2232-2248, 3580-3596)
  *   bottom      one 64-byte record per macroblock: what the row below needs from it
+ *   pend        per macroblock: its bottom lines until the row below has filtered them (h264e_mbpend_t)
  *   progress    one counter per macroblock row: macroblocks finished in that row (wavefront hand-off)
  *   rowbits     one bit buffer per macroblock row (MSB-first 32-bit words)
  *   mbrec       per macroblock {mv[0], type, used-candidates} for the mv_clusters validation
@@ -49,6 +50,16 @@ typedef struct
     uint8_t pad;
 } h264e_mbbottom_t;
 
+/* The bottom 4 luma / 2 chroma lines of a macroblock are not final until the row below has filtered the edge between
+ * them: they wait here (deblocked by their own macroblock and by its right neighbour) and the row below writes the final
+ * samples into the picture.  The picture therefore only ever holds final samples of rows that are complete, which is
+ * what lets a frame be encoded again from macroblock row `first_row` with everything above it kept. */
+typedef struct
+{
+    uint8_t y[64];                      /* luma rows 12..15 */
+    uint8_t c[2][16];                   /* chroma rows 6..7 of U, V */
+} h264e_mbpend_t;
+
 typedef struct
 {
     uint32_t nbits;                     /* bits in the row buffer */
@@ -88,6 +99,7 @@ typedef struct
 {
     uint8_t *rec[2][3];
     h264e_mbbottom_t *bottom;
+    h264e_mbpend_t *pend;               /* [nmb] */
     int *progress;
     uint32_t *rowbits;
     h264e_rowmeta_t *rowmeta;
@@ -114,6 +126,7 @@ typedef struct
     int arena_reset;                    /* the result goes to the start of the chain's arena (one result per chain slot) */
     const int *dep_progress;            /* progress counters of the job that builds `ref` in the SAME launch, or NULL when ref is complete */
     int frame_slot;
+    int first_row;                      /* macroblock rows above it are kept from the previous encode of this frame */
     int hdr_nbits;                      /* NAL header byte + slice header, MSB-aligned at bit hdr_nbits-1 */
     uint64_t hdr_bits;
     mv32 clusters[2];                   /* speculated mv_clusters state for every macroblock of the frame ... */

@@ -774,6 +774,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
     const size_t rbsp_cap = (size_t)nmb*640 + 2048;
     uint8_t *rbsp = (uint8_t *)malloc(rbsp_cap);      /* unused by the streaming path, kept for the size check */
     int32_t state[2] = { c->par.mv_clusters_in[0], c->par.mv_clusters_in[1] };
+    int first_row = 0;                      /* the frame that is encoded again restarts at the first divergent macroblock row */
     int32_t after[2] = { 0, 0 };            /* after a failed validation: predicted state behind the frame that is encoded again */
     int have_after = 0;
     uint16_t qdat_i[2][42], qdat_p[2][42];
@@ -812,6 +813,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             t->mv_clusters[0] = used[i][0] = (i && have_after) ? after[0] : state[0];
             t->mv_clusters[1] = used[i][1] = (i && have_after) ? after[1] : state[1];
             t->mv_clusters_per_mb = (i == 0) ? first_arr : NULL;
+            t->first_row = (i == 0 && first_arr) ? first_row : 0;
         }
         stats.rounds++;
         have_after = 0;
@@ -845,9 +847,13 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             {
                 /* exact walk: does every consumed (rounded) candidate equal what the kernel was given? */
                 int32_t cc[2] = { state[0], state[1] };
-                const int bad = clusters_walk(cc, h264e_hip_stream_mbrec(c->pool, slot), nmb, per_mb ? first_arr : used[i], per_mb, traj) >= 0;
+                const int first_bad = clusters_walk(cc, h264e_hip_stream_mbrec(c->pool, slot), nmb, per_mb ? first_arr : used[i], per_mb, traj);
+                const int bad = first_bad >= 0;
                 if (bad)
                 {
+                    /* every macroblock before first_bad consumed exactly the right candidates: its row and the rows above
+                     * it are bit-identical in the next encode and are kept */
+                    first_row = first_bad/c->seq.nmbx;
                     /* frames from here on are void: stop the launch, go again with exact per-macroblock values for this one */
                     if (h264e_hip_stream_abort(c->pool)) goto done;
                     if (!first_arr) first_arr = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb);
@@ -876,8 +882,8 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
         stats.encode_ms += now_ms() - t0;
         n += nvalid;
         if (getenv("H264E_DEBUG"))
-            fprintf(stderr, "clip launch %d: %d frames in flight, %d valid, next %d; first frame after %.2f ms, then %.3f ms/frame, drained %.2f ms after the last\n",
-                    stats.rounds, F, nvalid, n, t_first - t_submit, nvalid > 1 ? (t_last - t_first)/(nvalid - 1 + (nvalid < F)) : 0.0, now_ms() - t_last);
+            fprintf(stderr, "clip launch %d (first row %d): %d frames in flight, %d valid, next %d; first frame after %.2f ms, then %.3f ms/frame, drained %.2f ms after the last\n",
+                    stats.rounds, tasks[0].first_row, F, nvalid, n, t_first - t_submit, nvalid > 1 ? (t_last - t_first)/(nvalid - 1 + (nvalid < F)) : 0.0, now_ms() - t_last);
     }
     stats.mv_clusters_out[0] = state[0]; stats.mv_clusters_out[1] = state[1];
     stats.next_idr_pic_id_state = idr_state ^ (((c->nframes + G - 1)/G) & 1);

@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
     }
 
     /* ---- macroblock row */
+    if (row < T.first_row) return;          /* kept from the previous encode of this frame (its counter already says complete) */
     row_begin(L, G, C, T, row);
     int seen = 0, seen_dep = 0;
     const int dep_row = imin(row + H264E_DEP_ROWS, G.nmby - 1);
@@ -119,10 +120,22 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
         const int need_dep = T.dep_progress ? imin(x + H264E_DEP_COLS, G.nmbx) : 0;     /* temporal wavefront: h264e_dev.h */
         int st = 0;
         if (T.abort_word && uni(__hip_atomic_load((const GLOBAL_AS int *)T.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == T.launch_id) st = -2;
-        if (!st && (seen < need || seen_dep < need_dep))
+        /* temporal dependency first, then the loads that only need it (input, reference window) ... */
+        if (!st && seen_dep < need_dep)
         {
-            if (seen < need) st = poll_progress(C.progress + (row - 1), need, seen);
-            if (!st && seen_dep < need_dep) st = poll_progress((const GLOBAL_AS int *)T.dep_progress + dep_row, need_dep, seen_dep);
+            st = poll_progress((const GLOBAL_AS int *)T.dep_progress + dep_row, need_dep, seen_dep);
+            if (!st)
+            {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+        if (!st) row_prefetch(L, G, T, row, x);
+        /* ... so that their latency overlaps with the wait for the row above */
+        if (!st && seen < need)
+        {
+            st = poll_progress(C.progress + (row - 1), need, seen);
             if (!st)
             {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -258,6 +271,8 @@ struct h264e_hip_pool
     h264e_hip_mbrec_t **host_mbrec;      /* [nchains], each nmb records */
     uint32_t host_rbsp_cap;
     int *abort_word;                     /* host-mapped */
+    uint8_t *heap; size_t heap_bytes;    /* ONE device allocation; every device buffer of the pool is carved out of it */
+    uint8_t *hheap; size_t hheap_bytes;  /* ONE host-mapped allocation for the streaming mirrors */
     int launch_counter;
     int *slot_launch;                    /* per chain slot: launch id of its current job */
     int32_t **clu_dev;                   /* per chain: optional per-macroblock mv_clusters array */
@@ -291,19 +306,9 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
 #endif
-    if (p->chains_host)
-        for (int c = 0; c < p->nchains; c++)
-        {
-            h264e_chain_dev_t &C = p->chains_host[c];
-            dev_free(C.rec[0][0]); dev_free(C.bottom); dev_free(C.rowbits); dev_free(C.rowmeta);
-            dev_free(C.mbrec); dev_free(C.arena); dev_free(C.cursor); dev_free(C.fout); dev_free(C.prof);
-            if (p->clu_dev) dev_free(p->clu_dev[c]);
-        }
-    if (p->host_rbsp) for (int c = 0; c < p->nchains; c++) host_free(p->host_rbsp[c]);
-    if (p->host_mbrec) for (int c = 0; c < p->nchains; c++) host_free(p->host_mbrec[c]);
-    host_free(p->host_done); host_free(p->abort_word);
+    host_free(p->hheap);
     free(p->host_rbsp); free(p->host_mbrec); free(p->slot_launch);
-    dev_free(p->clip); dev_free(p->chains_dev); dev_free(p->tasks_dev); dev_free(p->progress_all); dev_free(p->errflag); dev_free(p->stepflags); dev_free(p->order);
+    dev_free(p->heap);
 #ifndef H264E_EMU
     if (p->stream)
     {
@@ -352,44 +357,60 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     p->host_rbsp = (uint8_t **)calloc((size_t)nchains, sizeof(uint8_t *));
     p->host_mbrec = (h264e_hip_mbrec_t **)calloc((size_t)nchains, sizeof(h264e_hip_mbrec_t *));
     int bad = 0;
-    bad |= dev_malloc((void **)&p->clip, p->frame_bytes*(size_t)frames_resident);
-    bad |= dev_malloc((void **)&p->chains_dev, sizeof(h264e_chain_dev_t)*(size_t)nchains);
-    bad |= dev_malloc((void **)&p->tasks_dev, sizeof(h264e_frame_task_t)*(size_t)nchains*TASK_RING);
-    bad |= dev_malloc((void **)&p->progress_all, sizeof(int)*(size_t)nchains*G.nmby);
-    bad |= dev_malloc((void **)&p->errflag, sizeof(int));
-    bad |= dev_malloc((void **)&p->stepflags, sizeof(int)*2*(size_t)nchains);
-    bad |= dev_malloc((void **)&p->order, sizeof(uint32_t)*(size_t)nchains*(G.nmby + 1));
     const size_t plane = (size_t)G.W*G.H*3/2;
     const uint32_t arena_cap = (uint32_t)((size_t)slots*((size_t)G.nmb*640 + 1024));
     p->host_rbsp_cap = (uint32_t)((size_t)G.nmb*640 + 1024);
-    bad |= host_malloc((void **)&p->host_done, sizeof(h264e_hostdone_t)*(size_t)nchains);
-    bad |= host_malloc((void **)&p->abort_word, 64);
-    for (int c = 0; c < nchains && !bad; c++)
+    /* One device allocation and one host-mapped allocation per pool, carved by a bump pointer: pass 0 sizes them, pass 1
+     * hands out the pointers.  (Hundreds of separate small allocations get small page-table fragments; one large block is
+     * mapped with large ones, and every macroblock touches about ten of these buffers.) */
+    for (int pass = 0; pass < 2 && !bad; pass++)
     {
-        h264e_chain_dev_t &C = p->chains_host[c];
-        uint8_t *rec = 0;
-        bad |= dev_malloc((void **)&rec, 2*plane);
-        if (bad) break;
-        for (int k = 0; k < 2; k++)
+        size_t pos = 0, hpos = 0;
+        uint8_t *base = pass ? p->heap : 0, *hbase = pass ? p->hheap : 0;
+        auto carve = [&](size_t n, size_t align) -> void * { pos = (pos + align - 1) & ~(align - 1); void *r = base ? base + pos : 0; pos += n ? n : 1; return r; };
+        auto hcarve = [&](size_t n) -> void * { hpos = (hpos + 255) & ~(size_t)255; void *r = hbase ? hbase + hpos : 0; hpos += n; return r; };
+        p->clip = (uint8_t *)carve(p->frame_bytes*(size_t)frames_resident, 4096);
+        p->chains_dev = (h264e_chain_dev_t *)carve(sizeof(h264e_chain_dev_t)*(size_t)nchains, 256);
+        p->tasks_dev = (h264e_frame_task_t *)carve(sizeof(h264e_frame_task_t)*(size_t)nchains*TASK_RING, 256);
+        p->progress_all = (int *)carve(sizeof(int)*(size_t)nchains*G.nmby, 256);
+        p->errflag = (int *)carve(sizeof(int), 256);
+        p->stepflags = (int *)carve(sizeof(int)*2*(size_t)nchains, 256);
+        p->order = (uint32_t *)carve(sizeof(uint32_t)*(size_t)nchains*(G.nmby + 1), 256);
+        p->host_done = (h264e_hostdone_t *)hcarve(sizeof(h264e_hostdone_t)*(size_t)nchains);
+        p->abort_word = (int *)hcarve(64);
+        for (int c = 0; c < nchains; c++)
         {
-            C.rec[k][0] = rec + k*plane;
-            C.rec[k][1] = C.rec[k][0] + (size_t)G.W*G.H;
-            C.rec[k][2] = C.rec[k][1] + (size_t)G.W*G.H/4;
+            h264e_chain_dev_t &C = p->chains_host[c];
+            uint8_t *rec = (uint8_t *)carve(2*plane, 4096);
+            for (int k = 0; k < 2; k++)
+            {
+                C.rec[k][0] = rec + k*plane;
+                C.rec[k][1] = C.rec[k][0] + (size_t)G.W*G.H;
+                C.rec[k][2] = C.rec[k][1] + (size_t)G.W*G.H/4;
+            }
+            C.bottom = (h264e_mbbottom_t *)carve(sizeof(h264e_mbbottom_t)*(size_t)G.nmb, 256);
+            C.pend = (h264e_mbpend_t *)carve(sizeof(h264e_mbpend_t)*(size_t)G.nmb, 256);
+            C.progress = p->progress_all + (size_t)c*G.nmby;
+            C.rowbits = (uint32_t *)carve(sizeof(uint32_t)*(size_t)G.nmby*G.row_words, 256);
+            C.rowmeta = (h264e_rowmeta_t *)carve(sizeof(h264e_rowmeta_t)*(size_t)G.nmby, 256);
+            C.mbrec = (h264e_mbrec_t *)carve(sizeof(h264e_mbrec_t)*(size_t)G.nmb*slots, 256);
+            C.arena = (uint8_t *)carve(arena_cap, 256);
+            C.arena_cap = arena_cap;
+            C.cursor = (uint32_t *)carve(16, 256);
+            C.fout = (h264e_frameout_t *)carve(sizeof(h264e_frameout_t)*(size_t)slots, 256);
+            C.prof = (unsigned long long *)carve(sizeof(unsigned long long)*32, 256);
+            p->clu_dev[c] = (int32_t *)carve(sizeof(int32_t)*2*(size_t)G.nmb, 256);      /* per-macroblock mv_clusters array of a re-encode */
+            if (slots == 1)        /* streaming pools keep one result per chain slot: give each a host-mapped mirror */
+            {
+                p->host_rbsp[c] = (uint8_t *)hcarve(p->host_rbsp_cap + 64);
+                p->host_mbrec[c] = (h264e_hip_mbrec_t *)hcarve(sizeof(h264e_hip_mbrec_t)*(size_t)G.nmb + 64);
+            }
         }
-        bad |= dev_malloc((void **)&C.bottom, sizeof(h264e_mbbottom_t)*(size_t)G.nmb);
-        C.progress = p->progress_all + (size_t)c*G.nmby;
-        bad |= dev_malloc((void **)&C.rowbits, sizeof(uint32_t)*(size_t)G.nmby*G.row_words);
-        bad |= dev_malloc((void **)&C.rowmeta, sizeof(h264e_rowmeta_t)*(size_t)G.nmby);
-        bad |= dev_malloc((void **)&C.mbrec, sizeof(h264e_mbrec_t)*(size_t)G.nmb*slots);
-        bad |= dev_malloc((void **)&C.arena, arena_cap);
-        C.arena_cap = arena_cap;
-        bad |= dev_malloc((void **)&C.cursor, 16);
-        bad |= dev_malloc((void **)&C.fout, sizeof(h264e_frameout_t)*(size_t)slots);
-        bad |= dev_malloc((void **)&C.prof, sizeof(unsigned long long)*32);
-        if (slots == 1)        /* streaming pools keep one result per chain slot: give each a host-mapped mirror */
+        if (!pass)
         {
-            bad |= host_malloc((void **)&p->host_rbsp[c], p->host_rbsp_cap + 64);
-            bad |= host_malloc((void **)&p->host_mbrec[c], sizeof(h264e_hip_mbrec_t)*(size_t)G.nmb + 64);
+            p->heap_bytes = pos + 4096; p->hheap_bytes = hpos + 4096;
+            bad |= dev_malloc((void **)&p->heap, p->heap_bytes);
+            bad |= host_malloc((void **)&p->hheap, p->hheap_bytes);
         }
     }
     if (bad)
@@ -400,8 +421,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
 #ifdef H264E_EMU
     memcpy(p->chains_dev, p->chains_host, sizeof(h264e_chain_dev_t)*(size_t)nchains);
 #else
-    for (int c = 0; c < nchains; c++) { (void)hipMemset(p->chains_host[c].cursor, 0, 16); (void)hipMemset(p->chains_host[c].prof, 0, 256); }
-    (void)hipMemset(p->errflag, 0, sizeof(int));
+    (void)hipMemset(p->heap, 0, p->heap_bytes);
     if (hipMemcpy(p->chains_dev, p->chains_host, sizeof(h264e_chain_dev_t)*(size_t)nchains, hipMemcpyHostToDevice) != hipSuccess)
     {
         h264e_hip_pool_destroy(p);
@@ -567,6 +587,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             p->ref_sel[c] ^= 1;
         }
         d.frame_slot = t.frame_slot;
+        d.first_row = (t.stream_mode && t.first_row > 0 && t.first_row < G.nmby) ? t.first_row : 0;
         d.hdr_nbits = t.hdr_nbits; d.hdr_bits = t.hdr_bits;
         d.clusters[0] = t.mv_clusters[0]; d.clusters[1] = t.mv_clusters[1];
         d.clusters_per_mb = 0;
@@ -574,7 +595,6 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         {
             const size_t n = sizeof(int32_t)*2*(size_t)G.nmb;
             const int cs = t.stream_mode ? t.slot : c;
-            if (!p->clu_dev[cs] && dev_malloc((void **)&p->clu_dev[cs], n)) { free(host); FAIL("device allocation failed"); }
 #ifdef H264E_EMU
             memcpy(p->clu_dev[cs], t.mv_clusters_per_mb, n);
 #else
@@ -602,11 +622,11 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         const h264e_frame_task_t &T = slot[c];
         if (!T.active) continue;
         const ChainG C = chain_view(p->chains_dev[T.chain]);
-        for (int row = 0; row < G.nmby; row++)
+        for (int row = T.first_row; row < G.nmby; row++)
         {
             RowLds *L = (RowLds *)calloc(1, sizeof(RowLds));
             row_begin(*L, G, C, T, row);
-            for (int x = 0; x < G.nmbx; x++) row_step(*L, G, C, T, row, x);
+            for (int x = 0; x < G.nmbx; x++) { row_prefetch(*L, G, T, row, x); row_step(*L, G, C, T, row, x); }
             row_end(*L, G, C, row);
             free(L);
         }
@@ -624,9 +644,20 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     HIPCHK(hipSetDevice(p->device));
     /* pageable source: the runtime stages the copy before returning, so `host` can be freed right away */
     hipError_t e = hipMemcpyAsync(slot, host, sizeof(h264e_frame_task_t)*(size_t)p->nchains, hipMemcpyHostToDevice, p->stream);
+    if (e != hipSuccess) { free(host); FAIL("task upload: %s", hipGetErrorString(e)); }
+    e = hipMemsetAsync(p->progress_all, 0, sizeof(int)*(size_t)p->nchains*G.nmby, p->stream);
+    /* rows kept from the previous encode of a frame count as complete */
+    for (int c = 0; c < p->nchains && e == hipSuccess; c++)
+        if (host[c].active && host[c].first_row > 0)
+        {
+            int *done = (int *)malloc(sizeof(int)*(size_t)host[c].first_row);
+            if (!done) { e = hipErrorOutOfMemory; break; }
+            for (int r = 0; r < host[c].first_row; r++) done[r] = G.nmbx + 1;
+            e = hipMemcpyAsync(p->chains_host[host[c].chain].progress, done, sizeof(int)*(size_t)host[c].first_row, hipMemcpyHostToDevice, p->stream);
+            free(done);         /* pageable source: staged before the call returns */
+        }
     free(host);
-    if (e != hipSuccess) FAIL("task upload: %s", hipGetErrorString(e));
-    HIPCHK(hipMemsetAsync(p->progress_all, 0, sizeof(int)*(size_t)p->nchains*G.nmby, p->stream));
+    if (e != hipSuccess) FAIL("progress reset: %s", hipGetErrorString(e));
     const int pe = p->ev_pending;
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][0], p->stream));
     hipLaunchKernelGGL(h264e_mb_kernel, dim3((unsigned)(p->nchains*(G.nmby + 1))), dim3(64), 0, p->stream,

@@ -43,6 +43,9 @@ typedef struct
      * task i builds the picture of chain slot `slot` and references the picture of `ref_slot` (-1: none, I slice),
      * which is either complete or (ref_in_flight) being built by an earlier task of this same submit, a few rows ahead */
     int stream_mode, slot, ref_slot, ref_in_flight;
+    /* stream mode: encode this frame again from macroblock row first_row; the rows above it (bits, records, picture) are
+     * kept from the previous encode of the same frame in the same slot (0 = whole frame) */
+    int first_row;
 } h264e_hip_task_t;
 
 typedef struct
