@@ -59,7 +59,7 @@ DEV void bw_put(BitW &b, int n, uint32_t v)
     if (b.nacc >= 32)
     {
         b.nacc -= 32;
-        if (b.pos < b.cap) b.buf[b.pos] = (uint32_t)(b.acc >> b.nacc);
+        if (b.pos < b.cap) { if (wave_lane() == 0) cstore32((gu8 *)(b.buf + b.pos), (uint32_t)(b.acc >> b.nacc)); }     /* read by the finalizer workgroup */
         else b.overflow = 1;
         b.pos++;
         b.acc &= (1ull << b.nacc) - 1;
@@ -84,9 +84,16 @@ struct Plane { const gu8 *p; int w, h, stride; };
 NOINLINE_DEV uint32_t ref_load4_border(const gu8 *row, int w, int x)
 {
     uint32_t v = 0;
-    for (int k = 0; k < 4; k++) v |= (uint32_t)row[imin(imax(x + k, 0), w - 1)] << (8*k);
+    for (int k = 0; k < 4; k++)
+    {
+        const int xx = imin(imax(x + k, 0), w - 1);
+        v |= ((cload32(row + (xx & ~3)) >> (8*(xx & 3))) & 255u) << (8*k);      /* rows start 4-byte aligned */
+    }
     return v;
 }
+
+/* two consecutive aligned dwords (4-byte aligned address), coherent */
+DEV uint64_t cload64x2(const gu8 *p) { return (uint64_t)cload32(p) | ((uint64_t)cload32(p + 4) << 32); }
 
 /* four samples (x..x+3, y) from HBM, little-endian packed, coordinates clamped to the picture: this IS the
  * reference's border extension (H:2232-2248) without storing the border */
@@ -94,7 +101,19 @@ DEV uint32_t ref_load4(const Plane &P, int x, int y)
 {
     y = imin(imax(y, 0), P.h - 1);
     const gu8 *r = P.p + (size_t)y*P.stride;
+#if !defined(H264E_EMU) && !H264E_COHERENT_LOADS
     if (x >= 0 && x + 3 < P.w) return gload32(r + x);
+#endif
+    if (x >= 0 && x + 7 < P.w)
+    {
+        /* unaligned 4 samples = two aligned coherent dwords + byte align (x + 7 < w keeps the second dword inside the row) */
+        const uint64_t d = cload64x2(r + (x & ~3));
+#ifdef H264E_EMU
+        return (uint32_t)(d >> (8*(x & 3)));
+#else
+        return __builtin_amdgcn_alignbyte((uint32_t)(d >> 32), (uint32_t)d, x & 3);
+#endif
+    }
     return ref_load4_border(r, P.w, x);
 }
 
@@ -158,9 +177,7 @@ DEV void rv_wait_rect(const RefView &V, int x1, int y1)
         if (++spins > (1u << 24)) break;            /* bounded: a stuck producer is reported by its own row loop */
         __builtin_amdgcn_s_sleep(8);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    consumer_acquire();
 #else
     (void)V; (void)x1; (void)y1;
 #endif
@@ -176,15 +193,14 @@ DEV void wave_load_window(uint8_t *win, const Plane &P, int wx0, int wy0)
         const int y = imin(imax(wy0 + l, 0), P.h - 1);
         if (interior)
         {
-            const GLOBAL_AS u32x4 *src = (const GLOBAL_AS u32x4 *)(P.p + (size_t)y*P.stride + wx0);   /* wx0 is a multiple of 8: dword aligned */
-            u32x4 v[WIN_W/16];
+            const gu8 *src = P.p + (size_t)y*P.stride + wx0;        /* wx0 is a multiple of 8 */
+            uint64_t v[WIN_W/8];
 #pragma unroll
-            for (int g = 0; g < WIN_W/16; g++) v[g] = src[g];
+            for (int g = 0; g < WIN_W/8; g++) v[g] = cload64(src + 8*g);
 #pragma unroll
-            for (int g = 0; g < WIN_W/16; g++)
+            for (int g = 0; g < WIN_W/8; g++)
             {
-                lds32_store(win + l*WIN_STRIDE + 16*g, v[g].x); lds32_store(win + l*WIN_STRIDE + 16*g + 4, v[g].y);
-                lds32_store(win + l*WIN_STRIDE + 16*g + 8, v[g].z); lds32_store(win + l*WIN_STRIDE + 16*g + 12, v[g].w);
+                lds32_store(win + l*WIN_STRIDE + 8*g, (uint32_t)v[g]); lds32_store(win + l*WIN_STRIDE + 8*g + 4, (uint32_t)(v[g] >> 32));
             }
         } else
         {

@@ -25,10 +25,12 @@ struct RowLds
     mv32 df_mv[25];
     int left_type, left_qp;
     alignas(4) uint8_t strip_y[16*4];               /* deblocked columns 12..15 of the left macroblock (luma), 6..7 (chroma) */
-    alignas(4) uint8_t strip_c[2][8*2];
+    alignas(4) uint8_t strip_c[2][8*4];             /* columns 4..7 of the left macroblock's chroma (final except column 7) */
+    alignas(4) uint8_t trec[72];                    /* staged record of the macroblock above (+ 8 bytes of the one above-right) */
+    alignas(4) uint8_t brec[64];                    /* record of this macroblock for the row below, assembled here */
     BitW bw;
     int skip_run, lead_skips, coded_any;
-    unsigned long long prof[32], prof_last;
+    unsigned long long prof[32], prof_last, prof_c0, prof_w0;
 
     /* ---- per macroblock */
     mv32 mv_top[8];

@@ -47,7 +47,7 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
         if (l < 32) L.pix_left[l] = 0;
         if (l < 25) L.df_mv[l] = 0;
         L.strip_y[l] = 0;
-        if (l < 32) L.strip_c[l >> 4][l & 15] = 0;
+        L.strip_c[l >> 5][l & 31] = 0;
     }
     L.df_nzflag = 0;
     L.left_type = 0;
@@ -64,30 +64,40 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
     cavlc_tab_load(L.cavlc);
     for (int i = 0; i < 32; i++) L.prof[i] = 0;
     L.prof_last = 0;
+#if defined(H264E_STAMPS) && !defined(H264E_EMU)
+    L.prof_c0 = __builtin_readcyclecounter(); L.prof_w0 = wall_clock64();      /* shader-clock cycles vs constant 100 MHz clock: effective frequency */
+#endif
     wave_sync();
     STAMP(L, 31);
     L.prof[31] = 0;
 }
 
-/* neighbour record of the macroblock above -> LDS (h264-lab.h:742-745 contexts, :590-606 deblock state) */
+/* neighbour record of the macroblock above -> LDS (h264-lab.h:742-745 contexts, :590-606 deblock state): 16 coherent dword
+ * loads of the record (+2 of the record to its right), staged in LDS, then unpacked */
 DEV void load_top(RowLds &L, const h264e_geom_t &G, const GLOBAL_AS h264e_mbbottom_t *above, int x, int have_top)
 {
-    WAVE_FOR(l)
+    if (have_top)
     {
-        if (have_top)
+        WAVE_FOR(l)
         {
-            const GLOBAL_AS h264e_mbbottom_t &B = above[x];
-            if (l < 8) L.pix_top[4*l + 0] = B.pix[4*l + 0], L.pix_top[4*l + 1] = B.pix[4*l + 1], L.pix_top[4*l + 2] = B.pix[4*l + 2], L.pix_top[4*l + 3] = B.pix[4*l + 3];
-            else if (l < 12) L.mv_top[l - 8] = B.mv[l - 8];
-            else if (l < 20) L.nnz_top[l - 12] = B.nnz[l - 12];
-            else if (l < 24) L.i4_top[l - 20] = B.i4[l - 20];
-            else if (l == 24) { L.df_nz_top = B.df_nz; L.top_type = B.type; L.top_qp = B.qp; }
-            else if (l < 29)
-            {
-                int k = l - 25;
-                L.pix_top[32 + k] = x + 1 < G.nmbx ? above[x + 1].pix[k] : 0;
-            } else if (l == 29) L.mv_top[4] = x + 1 < G.nmbx ? above[x + 1].mv[0] : 0;
-        } else
+            if (l < 16) lds32_store(L.trec + 4*l, cload32((const gu8 *)(above + x) + 4*l));
+            else if (l == 16) lds32_store(L.trec + 64, x + 1 < G.nmbx ? cload32((const gu8 *)(above + x + 1)) : 0u);                /* pix[0..3] of the above-right record */
+            else if (l == 17) lds32_store(L.trec + 68, x + 1 < G.nmbx ? cload32((const gu8 *)(above + x + 1) + 32) : 0u);           /* its mv[0] */
+        }
+        wave_sync();
+        WAVE_FOR(l)
+        {
+            if (l < 8) lds32_store(L.pix_top + 4*l, lds32(L.trec + 4*l));
+            else if (l < 12) L.mv_top[l - 8] = (mv32)lds32(L.trec + 32 + 4*(l - 8));
+            else if (l < 20) L.nnz_top[l - 12] = L.trec[48 + l - 12];
+            else if (l < 24) L.i4_top[l - 20] = (int8_t)L.trec[56 + l - 20];
+            else if (l == 24) { L.df_nz_top = L.trec[60]; L.top_type = (int8_t)L.trec[61]; L.top_qp = L.trec[62]; }
+            else if (l == 25) lds32_store(L.pix_top + 32, lds32(L.trec + 64));
+            else if (l == 26) L.mv_top[4] = (mv32)lds32(L.trec + 68);
+        }
+    } else
+    {
+        WAVE_FOR(l)
         {
             if (l < 36) L.pix_top[l] = 0;
             if (l < 5) L.mv_top[l] = 0;
@@ -186,27 +196,27 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
     /* record for the mv_clusters validation (h264-lab.h:5776-5779 updates them with mv[0] of every non-intra MB) */
     {
         GLOBAL_AS h264e_mbrec_t *rec = C.mbrec + (size_t)T.frame_slot*G.nmb + m.num;
-        rec->mv0 = m.type < 5 ? L.mv[0] : 0;
-        rec->type = (int8_t)m.type;
-        rec->used_cand = (uint8_t)m.used_cand;
+        const uint32_t mv0 = m.type < 5 ? (uint32_t)L.mv[0] : 0u;
+        const uint64_t w = (uint64_t)mv0 | ((uint64_t)(uint8_t)(int8_t)m.type << 32) | ((uint64_t)(m.used_cand & 255) << 40);
+        if (wave_lane() == 0) cstore64((gu8 *)rec, w);
     }
 
     /* keep the UNFILTERED right column / bottom row for intra prediction (h264-lab.h:4693-4714) */
     uint8_t *ty = L.ytile + 4*YT_STRIDE + 4;
     uint8_t *tc0 = L.ctile[0] + 2*CT_STRIDE + 2, *tc1 = L.ctile[1] + 2*CT_STRIDE + 2;
-    GLOBAL_AS h264e_mbbottom_t &B = rowrec[x];
+    /* the record for the row below is assembled in LDS (L.brec) and stored at the end of the step */
     WAVE_FOR(l)
     {
         if (l < 16)
         {
             L.pix_left[l] = ty[YT_STRIDE*l + 15];
-            B.pix[l] = ty[YT_STRIDE*15 + l];
+            L.brec[l] = ty[YT_STRIDE*15 + l];
         } else if (l < 32)
         {
             int pl = (l >> 3) & 1, i = l & 7;
             const uint8_t *t = pl ? tc1 : tc0;
             L.pix_left[16 + 8*pl + i] = t[CT_STRIDE*i + 7];
-            B.pix[16 + 8*pl + i] = t[CT_STRIDE*7 + i];
+            L.brec[16 + 8*pl + i] = t[CT_STRIDE*7 + i];
         } else if (l < 35)
         {
             int c = l - 32;
@@ -232,18 +242,18 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
             {
                 int pl = (l >> 3) & 1, i = l & 7;
                 uint8_t *t = L.ctile[pl] + (2 + i)*CT_STRIDE;
-                t[0] = L.strip_c[pl][2*i]; t[1] = L.strip_c[pl][2*i + 1];
+                t[0] = L.strip_c[pl][4*i + 2]; t[1] = L.strip_c[pl][4*i + 3];
             } else if (l < 48)
             {
                 int r = (l - 32) >> 2, c = l & 3;
                 uint32_t v = 0;
-                if (row > 0) v = gload32((const gu8 *)(pend_row - G.nmbx)[x].y + 16*r + 4*c);
+                if (row > 0) v = cload32((const gu8 *)(pend_row - G.nmbx)[x].y + 16*r + 4*c);
                 lds32_store(L.ytile + r*YT_STRIDE + 4 + 4*c, v);
             } else if (l < 56)
             {
                 int pl = (l >> 2) & 1, r = (l >> 1) & 1, c = l & 1;
                 uint32_t v = 0;
-                if (row > 0) v = gload32((const gu8 *)(pend_row - G.nmbx)[x].c[pl] + 8*r + 4*c);
+                if (row > 0) v = cload32((const gu8 *)(pend_row - G.nmbx)[x].c[pl] + 8*r + 4*c);
                 memcpy(L.ctile[pl] + r*CT_STRIDE + 2 + 4*c, &v, 4);
             }
         }
@@ -255,14 +265,14 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
     {
         int r = l >> 2, c = l & 3;
         uint32_t v = lds32(ty + YT_STRIDE*r + 4*c);
-        if (r < 12 || direct) gstore32(dy + (size_t)r*W + 4*c, v);
-        else gstore32((gu8 *)pend_row[x].y + 16*(r - 12) + 4*c, v);
+        if (r < 12 || direct) cstore32(dy + (size_t)r*W + 4*c, v);
+        else cstore32((gu8 *)pend_row[x].y + 16*(r - 12) + 4*c, v);
         if (l < 32)
         {
             int pl = l >> 4, rr = (l >> 1) & 7, g = l & 1;
             uint32_t u = lds32((pl ? tc1 : tc0) + CT_STRIDE*rr + 4*g);
-            if (rr < 6 || direct) gstore32((pl ? dv : du) + (size_t)rr*Wc + 4*g, u);
-            else gstore32((gu8 *)pend_row[x].c[pl] + 8*(rr - 6) + 4*g, u);
+            if (rr < 6 || direct) cstore32((pl ? dv : du) + (size_t)rr*Wc + 4*g, u);
+            else cstore32((gu8 *)pend_row[x].c[pl] + 8*(rr - 6) + 4*g, u);
         }
     }
     if (!T.no_deblock)
@@ -276,49 +286,53 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
                 if (x > 0)
                 {
                     uint32_t v = lds32(L.ytile + (4 + l)*YT_STRIDE);
-                    if (l < 12 || direct) gstore32(dy + (size_t)l*W - 4, v);
-                    else gstore32((gu8 *)pend_row[x - 1].y + 16*(l - 12) + 12, v);
+                    if (l < 12 || direct) cstore32(dy + (size_t)l*W - 4, v);
+                    else cstore32((gu8 *)pend_row[x - 1].y + 16*(l - 12) + 12, v);
                 }
             } else if (l < 32)
             {
                 int r = (l - 16) >> 2, c = l & 3;                           /* tile rows 0..3 = picture rows -4..-1 */
-                if (row > 0) { uint32_t v = lds32(L.ytile + r*YT_STRIDE + 4 + 4*c); gstore32(dy - (size_t)(4 - r)*W + 4*c, v); }
+                if (row > 0) { uint32_t v = lds32(L.ytile + r*YT_STRIDE + 4 + 4*c); cstore32(dy - (size_t)(4 - r)*W + 4*c, v); }
             } else if (l < 48)
             {
                 int pl = (l - 32) >> 3, i = (l - 32) & 7;
                 if (x > 0)
                 {
-                    const uint8_t b1 = L.ctile[pl][(2 + i)*CT_STRIDE + 1];
-                    if (i < 6 || direct) (pl ? dv : du)[(size_t)i*Wc - 1] = b1;
-                    else ((gu8 *)pend_row[x - 1].c[pl])[8*(i - 6) + 7] = b1;
+                    /* columns 4..7 of the left macroblock as one dword: 4..6 as it left them, 7 as this filter left it */
+                    const uint32_t v = (uint32_t)L.strip_c[pl][4*i] | ((uint32_t)L.strip_c[pl][4*i + 1] << 8) | ((uint32_t)L.strip_c[pl][4*i + 2] << 16) |
+                                       ((uint32_t)L.ctile[pl][(2 + i)*CT_STRIDE + 1] << 24);
+                    if (i < 6 || direct) cstore32((pl ? dv : du) + (size_t)i*Wc - 4, v);
+                    else cstore32((gu8 *)pend_row[x - 1].c[pl] + 8*(i - 6) + 4, v);
                 }
             } else if (l < 56)
             {
                 int pl = (l - 48) >> 2, r = (l >> 1) & 1, c = l & 1;       /* tile rows 0..1 = picture rows -2..-1 */
-                if (row > 0) { uint32_t v; memcpy(&v, L.ctile[pl] + r*CT_STRIDE + 2 + 4*c, 4); gstore32((pl ? dv : du) - (size_t)(2 - r)*Wc + 4*c, v); }
+                if (row > 0) { uint32_t v; memcpy(&v, L.ctile[pl] + r*CT_STRIDE + 2 + 4*c, 4); cstore32((pl ? dv : du) - (size_t)(2 - r)*Wc + 4*c, v); }
             }
         }
     }
-    /* carried deblock state: deblocked right columns of this macroblock */
+    /* carried deblock state: deblocked right columns of this macroblock; rest of the record for the row below */
     WAVE_FOR(l)
     {
         if (l < 16) lds32_store(L.strip_y + 4*l, lds32(ty + YT_STRIDE*l + 12));
         else if (l < 32)
         {
             int pl = (l >> 3) & 1, i = l & 7;
-            const uint8_t *t = (pl ? tc1 : tc0) + CT_STRIDE*i + 6;
-            L.strip_c[pl][2*i] = t[0]; L.strip_c[pl][2*i + 1] = t[1];
-        } else if (l < 36) B.mv[l - 32] = L.mv_top[l - 32];
-        else if (l < 44) B.nnz[l - 36] = L.nnz_top[l - 36];
-        else if (l < 48) B.i4[l - 44] = L.i4_top[l - 44];
+            const uint8_t *t = (pl ? tc1 : tc0) + CT_STRIDE*i + 4;
+            L.strip_c[pl][4*i] = t[0]; L.strip_c[pl][4*i + 1] = t[1]; L.strip_c[pl][4*i + 2] = t[2]; L.strip_c[pl][4*i + 3] = t[3];
+        } else if (l < 36) lds32_store(L.brec + 32 + 4*(l - 32), (uint32_t)L.mv_top[l - 32]);
+        else if (l < 44) L.brec[48 + l - 36] = L.nnz_top[l - 36];
+        else if (l < 48) L.brec[56 + l - 44] = (uint8_t)L.i4_top[l - 44];
         else if (l == 48)
         {
-            B.df_nz = (uint8_t)(L.df_nzflag >> 20);
-            B.type = (int8_t)m.type;
-            B.qp = (uint8_t)T.qp;
-            B.pad = 0;
+            L.brec[60] = (uint8_t)(L.df_nzflag >> 20);
+            L.brec[61] = (uint8_t)(int8_t)m.type;
+            L.brec[62] = (uint8_t)T.qp;
+            L.brec[63] = 0;
         }
     }
+    wave_sync();
+    WAVE_FOR(l) { if (l < 16) cstore32((gu8 *)(rowrec + x) + 4*l, lds32(L.brec + 4*l)); }
     L.left_type = m.type;
     L.left_qp = T.qp;
     wave_sync();
@@ -336,13 +350,18 @@ DEV void row_end(RowLds &L, const h264e_geom_t &G, const ChainG &C, int row)
         const int pad = 32 - bw.nacc;
         bw_put(bw, pad, 0);
     }
-    GLOBAL_AS h264e_rowmeta_t &M = C.rowmeta[row];
-    M.nbits = nbits;
-    M.lead_skips = L.coded_any ? L.lead_skips : G.nmbx;
-    M.trail_skips = L.coded_any ? L.skip_run : 0;
-    M.overflow = bw.overflow;
+    gu8 *M = (gu8 *)(C.rowmeta + row);       /* {nbits, lead_skips, trail_skips, overflow}: read by the finalizer workgroup */
+    if (wave_lane() == 0)
+    {
+        cstore32(M, nbits);
+        cstore32(M + 4, (uint32_t)(L.coded_any ? L.lead_skips : G.nmbx));
+        cstore32(M + 8, (uint32_t)(L.coded_any ? L.skip_run : 0));
+        cstore32(M + 12, (uint32_t)bw.overflow);
+    }
     wave_sync();
 #if defined(H264E_STAMPS) && !defined(H264E_EMU)
+    L.prof[28] = __builtin_readcyclecounter() - L.prof_c0; L.prof[29] = wall_clock64() - L.prof_w0;
+    wave_sync();
     if (threadIdx.x < 32 && C.prof) atomicAdd(C.prof + threadIdx.x, L.prof[threadIdx.x]);
 #endif
 }

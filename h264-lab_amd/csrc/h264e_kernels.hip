@@ -115,33 +115,24 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
     const int dep_row = imin(row + H264E_DEP_ROWS, G.nmby - 1);
     for (int x = 0; x < G.nmbx; x++)
     {
-        /* consumer: relaxed polls, then ONE agent-scope acquire (invalidates this CU's L1) */
+        /* consumer: relaxed sc1 polls, then sc1 loads of everything handed over */
         const int need = row > 0 ? imin(x + 2, G.nmbx) : 0;
         const int need_dep = T.dep_progress ? imin(x + H264E_DEP_COLS, G.nmbx) : 0;     /* temporal wavefront: h264e_dev.h */
         int st = 0;
-        if (T.abort_word && uni(__hip_atomic_load((const GLOBAL_AS int *)T.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == T.launch_id) st = -2;
+        /* the abort word lives in host memory (one PCIe read): look at it every 8th macroblock only */
+        if ((x & 7) == 0 && T.abort_word && uni(__hip_atomic_load((const GLOBAL_AS int *)T.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == T.launch_id) st = -2;
         /* temporal dependency first, then the loads that only need it (input, reference window) ... */
         if (!st && seen_dep < need_dep)
         {
             st = poll_progress((const GLOBAL_AS int *)T.dep_progress + dep_row, need_dep, seen_dep);
-            if (!st)
-            {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
+            if (!st) consumer_acquire();
         }
         if (!st) row_prefetch(L, G, T, row, x);
         /* ... so that their latency overlaps with the wait for the row above */
         if (!st && seen < need)
         {
             st = poll_progress(C.progress + (row - 1), need, seen);
-            if (!st)
-            {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
+            if (!st) consumer_acquire();
         }
         if (st)
         {
@@ -155,26 +146,17 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
         }
         STAMP(L, 13);
         row_step(L, G, C, T, row, x);
-        /* producer: drain every lane's stores, agent-scope release (L2 write-back), then the counter */
+        /* producer: every handed-off byte was stored write-through (sc1, wave.h cstore*): drain them, then the counter --
+         * no agent-scope release (L2 write-back) needed */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0)
-        {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(C.progress + row, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (threadIdx.x == 0) __hip_atomic_store(C.progress + row, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         STAMP(L, 14);
     }
     row_end(L, G, C, row);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(C.progress + row, G.nmbx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* row buffer + meta complete */
-    }
+    if (threadIdx.x == 0) __hip_atomic_store(C.progress + row, G.nmbx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* row buffer + meta complete */
 }
 
 #endif

@@ -161,6 +161,42 @@ typedef GLOBAL_AS u32_unaligned gu32u;
 DEV uint32_t gload32(const gu8 *p) { return *(const gu32u *)p; }
 DEV void gstore32(gu8 *p, uint32_t v) { *(gu32u *)p = v; }
 
+/*
+ * Coherent accessors for every byte that one workgroup writes and another reads INSIDE a launch (pictures, neighbour
+ * records, pending lines, bit buffers, macroblock records): `sc1` write-through stores and `sc1` loads (relaxed
+ * agent-scope atomics).  With every such byte stored and loaded this way, a hand-off needs no agent-scope release
+ * (L2 write-back) and no acquire (L1 invalidate) -- only: stores, s_waitcnt vmcnt(0), counter store | counter poll,
+ * loads (MI355X_MICROARCH.md "Valid forms").  Naturally aligned 4- or 8-byte accesses only.
+ */
+#ifdef H264E_EMU
+DEV uint32_t cload32(const gu8 *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+DEV uint64_t cload64(const gu8 *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+DEV void cstore32(gu8 *p, uint32_t v) { memcpy(p, &v, 4); }
+DEV void cstore64(gu8 *p, uint64_t v) { memcpy(p, &v, 8); }
+#else
+/* H264E_COHERENT_LOADS = 1: sc1 loads, the consumer needs no acquire.  0: plain loads behind ONE agent-scope acquire per
+ * hand-off (invalidates the CU's L1), the form cdna_hip_programming.md Guideline 16 recommends with write-through stores. */
+#ifndef H264E_COHERENT_LOADS
+#define H264E_COHERENT_LOADS 0
+#endif
+#if H264E_COHERENT_LOADS
+DEV uint32_t cload32(const gu8 *p) { return __hip_atomic_load((const GLOBAL_AS uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV uint64_t cload64(const gu8 *p) { return __hip_atomic_load((const GLOBAL_AS uint64_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void consumer_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+#else
+DEV uint32_t cload32(const gu8 *p) { return *(const GLOBAL_AS uint32_t *)p; }
+DEV uint64_t cload64(const gu8 *p) { return *(const GLOBAL_AS uint64_t *)p; }
+DEV void consumer_acquire()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+#endif
+DEV void cstore32(gu8 *p, uint32_t v) { __hip_atomic_store((GLOBAL_AS uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void cstore64(gu8 *p, uint64_t v) { __hip_atomic_store((GLOBAL_AS uint64_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+
 DEV int imin(int a, int b) { return a < b ? a : b; }
 DEV int imax(int a, int b) { return a > b ? a : b; }
 DEV int iabs(int x) { return x < 0 ? -x : x; }
