@@ -370,6 +370,57 @@ NOINLINE_DEV uint32_t interp4_hbm(const gu8 *p, int w, int h, int stride, int x,
     return interp_core([&](int dx, int dy) -> uint32_t { return ref_load4(P, x + dx, y + dy); }, fx, fy);
 }
 
+/*
+ * The three half-sample neighbours the sub-pel search needs around a full-pel position, in one pass over the window:
+ * at = window pointer at integer sample (ix, iy), the top-left of the 2x2 integer cell that contains all of them;
+ * (ox, oy) in {0,1}^2 = offset of the full-pel position (x, y) inside that cell.  Returns {full-pel samples at (x,y),
+ * horizontal half sample on row y, vertical half sample in column x, centre half sample}, 4 samples each.  Same
+ * arithmetic as interp_core for (2,0), (0,2) and (2,2): six rows are loaded once, their six horizontal filters serve the
+ * centre sample and (row y) the horizontal one, the vertical filter runs on the integer columns of the same rows.
+ */
+struct hp4_t { uint32_t x, y, z, w; };
+DEV int shr_opaque(int v, int s)
+{
+    int t = v >> s;
+#ifndef H264E_EMU
+    asm volatile("" : "+v"(t));
+#endif
+    return t;
+}
+NOINLINE_DEV hp4_t halfpel3_win(const lu8 *at, int ox, int oy)
+{
+    int th[6][4], cx[6][4];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+    {
+        const lu8 *q = at + (r - 2)*WIN_STRIDE;
+        const uint32_t a = lds32u(q - 4), b = lds32u(q), c = lds32u(q + 4);
+        int p[12];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { p[k] = (int)((a >> (8*k)) & 255); p[4 + k] = (int)((b >> (8*k)) & 255); p[8 + k] = (int)((c >> (8*k)) & 255); }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            th[r][i] = tap6(p[i + 2], p[i + 3], p[i + 4], p[i + 5], p[i + 6], p[i + 7]);
+            cx[r][i] = ox ? p[5 + i] : p[4 + i];
+        }
+    }
+    hp4_t o;
+    o.x = o.y = o.z = o.w = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const int f0 = oy ? cx[3][i] : cx[2][i];
+        /* shr_opaque: keeps the compiler from fusing "shift, clamp, pack" of two results into v_ashr_pk_u8_i32, whose
+         * results did not match the separate instructions on gfx950 (ROCm 7.2) in this function */
+        const int fh = clip255(shr_opaque((oy ? th[3][i] : th[2][i]) + 16, 5));
+        const int fv = clip255(shr_opaque(tap6(cx[0][i], cx[1][i], cx[2][i], cx[3][i], cx[4][i], cx[5][i]) + 16, 5));
+        const int fd = clip255(shr_opaque(tap6(th[0][i], th[1][i], th[2][i], th[3][i], th[4][i], th[5][i]) + 512, 10));
+        o.x |= (uint32_t)f0 << (8*i); o.y |= (uint32_t)fh << (8*i); o.z |= (uint32_t)fv << (8*i); o.w |= (uint32_t)fd << (8*i);
+    }
+    return o;
+}
+
 /* 4 interpolated samples at integer position (x,y); `inside` (wave-uniform) says the block's footprint is in the window */
 DEV uint32_t interp_luma4(const RefView &R, bool inside, int x, int y, int fx, int fy)
 {

@@ -314,13 +314,27 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
         const int fx0 = px + (mvx(mv) >> 2), fy0 = py + (mvy(mv) >> 2);
         const bool inside = rv_inside(R, fx0 - 5, fy0 - 3, fx0 + w + 4, fy0 + h + 3);      /* every probe is within one sample of mv */
         if (!inside) rv_wait_rect(R, fx0 + w + 4, fy0 + h + 3);
+        /* the 2x2 integer cell that holds the three half-sample positions: vdg = (+-1, +-1) says on which side of (x,y) it lies */
+        const int hp_ox = mvx(vdg) < 0 ? 1 : 0, hp_oy = mvy(vdg) < 0 ? 1 : 0, hp_pq_vertical = mvx(pq) == 0;
         wave_sum8([&](int l, int *sv) {
             if (l >= n) return;
             const int r = l >> (g >> 1), c4 = l & (g - 1), o = 16*r + 4*c4;
             const uint32_t in4 = lds32(b + o);
 #define IP(vv) interp_luma4(R, inside, px + (mvx(vv) >> 2) + 4*c4, py + (mvy(vv) >> 2) + r, mvx(vv) & 3, mvy(vv) & 3)
 #define AVG4(x, y) (((x) | (y)) - ((((x) ^ (y)) >> 1) & 0x7f7f7f7fu))                    /* per-byte (x + y + 1) >> 1 */
-            const uint32_t q00 = IP(mv), q02 = IP(v02), q20 = IP(v20), q22 = IP(v22);
+            uint32_t q00, q02, q20, q22;
+            if (inside)
+            {
+                /* all three half-sample planes from one pass over the window (halfpel3_win) */
+                const int ox = hp_ox, oy = hp_oy;
+                const hp4_t hp = halfpel3_win(rv_ptr(R, fx0 + 4*c4 - ox, fy0 + r - oy), ox, oy);
+                q00 = hp.x; q22 = hp.w;
+                q02 = hp_pq_vertical ? hp.z : hp.y;
+                q20 = hp_pq_vertical ? hp.y : hp.z;
+            } else
+            {
+                q00 = IP(mv); q02 = IP(v02); q20 = IP(v20); q22 = IP(v22);
+            }
 #undef IP
             const uint32_t q01 = AVG4(q00, q02), q10 = AVG4(q00, q20), q11 = AVG4(q02, q20), q12 = AVG4(q22, q02);
 #undef AVG4

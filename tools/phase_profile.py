@@ -41,6 +41,8 @@ def main():
               (t[18] / nmb, t[19] / t[18], t[17] / t[18], t[16] / max(t[17], 1), t[23] / t[18]))
 
 
+        if t[15] or t[30]:
+            print("halfpel3 mismatches: q00 %d  q02 %d  q20 %d  q22 %d" % (t[15], t[30] & 0xfffff, (t[30] >> 20) & 0xfffff, t[30] >> 40))
         if t[29]:
             print("effective shader clock over the rows' lifetimes: %.0f MHz (cycle counter / 100 MHz wall clock)" % (100.0 * t[28] / t[29]))
         if t[24] or t[25]:
