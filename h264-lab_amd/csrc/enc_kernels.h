@@ -1076,7 +1076,17 @@ DEV void df_chroma(uint8_t *p, int s, int alpha, int beta, int tc0, int bs)
  * chroma: lanes 0..7 U, 8..15 V.  An edge whose FIRST strength is 4 is strong-filtered over all 16
  * samples (H:1517, H:1534).
  */
-DEV void wave_deblock(uint8_t *yt, uint8_t *ct0, uint8_t *ct1, const uint8_t *bs, int qp, int qp_left, int qp_top)
+/* the deblocking tables of tables.h in LDS (global-memory table reads on every edge were a large part of the filter's time) */
+struct DfTab { uint8_t alpha[52], beta[52], tc0[52][3], qpc[52]; };
+DEV void df_tab_load(DfTab &t)
+{
+    WAVE_FOR(l)
+    {
+        if (l < 52) { t.alpha[l] = k_df_alpha[l]; t.beta[l] = k_df_beta[l]; t.qpc[l] = k_qpc[l]; t.tc0[l][0] = k_df_tc0[l][0]; t.tc0[l][1] = k_df_tc0[l][1]; t.tc0[l][2] = k_df_tc0[l][2]; }
+    }
+}
+
+DEV void wave_deblock(uint8_t *yt, uint8_t *ct0, uint8_t *ct1, const uint8_t *bs, int qp, int qp_left, int qp_top, const DfTab &D)
 {
     for (int dir = 0; dir < 2; dir++)
         for (int e = 0; e < 4; e++)
@@ -1084,7 +1094,7 @@ DEV void wave_deblock(uint8_t *yt, uint8_t *ct0, uint8_t *ct1, const uint8_t *bs
             const uint8_t *s = bs + 16*dir + 4*e;
             if (!(s[0] | s[1] | s[2] | s[3])) continue;
             int q = e ? qp : dir ? (qp_top + qp + 1) >> 1 : (qp_left + qp + 1) >> 1;
-            int alpha = k_df_alpha[q], beta = k_df_beta[q];
+            int alpha = D.alpha[q], beta = D.beta[q];
             if (s[0] != 4 && !alpha) continue;
             WAVE_FOR(l)
             {
@@ -1093,18 +1103,18 @@ DEV void wave_deblock(uint8_t *yt, uint8_t *ct0, uint8_t *ct1, const uint8_t *bs
                     uint8_t *p = dir ? yt + (4 + 4*e)*YT_STRIDE + 4 + l : yt + (4 + l)*YT_STRIDE + 4 + 4*e;
                     int across = dir ? YT_STRIDE : 1, st = s[l >> 2];
                     if (s[0] == 4) df_luma_strong(p, across, alpha, beta);
-                    else if (st) df_luma_normal(p, across, alpha, beta, st < 4 ? k_df_tc0[q][st - 1] : beta);
+                    else if (st) df_luma_normal(p, across, alpha, beta, st < 4 ? D.tc0[q][st - 1] : beta);
                 }
             }
             wave_sync();
         }
-    const int cq = k_qpc[qp], cql = k_qpc[qp_left], cqt = k_qpc[qp_top];
+    const int cq = D.qpc[qp], cql = D.qpc[qp_left], cqt = D.qpc[qp_top];
     for (int dir = 0; dir < 2; dir++)
         for (int e = 0; e < 4; e += 2)
         {
             const uint8_t *s = bs + 16*dir + 4*e;
             int q = e ? cq : dir ? (cqt + cq + 1) >> 1 : (cql + cq + 1) >> 1;
-            int alpha = k_df_alpha[q], beta = k_df_beta[q];
+            int alpha = D.alpha[q], beta = D.beta[q];
             if (!(s[0] | s[1] | s[2] | s[3]) || !alpha) continue;
             WAVE_FOR(l)
             {
@@ -1113,7 +1123,7 @@ DEV void wave_deblock(uint8_t *yt, uint8_t *ct0, uint8_t *ct1, const uint8_t *bs
                     uint8_t *t = (l & 8) ? ct1 : ct0;
                     int i = l & 7, st = s[i >> 1];
                     uint8_t *p = dir ? t + (2 + 2*e)*CT_STRIDE + 2 + i : t + (2 + i)*CT_STRIDE + 2 + 2*e;
-                    df_chroma(p, dir ? CT_STRIDE : 1, alpha, beta, (st && st < 4) ? k_df_tc0[q][st - 1] : 0, st);
+                    df_chroma(p, dir ? CT_STRIDE : 1, alpha, beta, (st && st < 4) ? D.tc0[q][st - 1] : 0, st);
                 }
             }
             wave_sync();

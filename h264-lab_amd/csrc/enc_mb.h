@@ -26,6 +26,7 @@ struct RowLds
     int left_type, left_qp;
     alignas(4) uint8_t strip_y[16*4];               /* deblocked columns 12..15 of the left macroblock (luma), 6..7 (chroma) */
     alignas(4) uint8_t strip_c[2][8*4];             /* columns 4..7 of the left macroblock's chroma (final except column 7) */
+    alignas(4) uint8_t ptop[96];                    /* pending bottom lines of the macroblock above (h264e_mbpend_t), fetched with its record */
     alignas(4) uint8_t trec[72];                    /* staged record of the macroblock above (+ 8 bytes of the one above-right) */
     alignas(4) uint8_t brec[64];                    /* record of this macroblock for the row below, assembled here */
     BitW bw;
@@ -44,6 +45,8 @@ struct RowLds
     alignas(4) uint8_t bs[32];
     I4Scratch i4s;
     CavlcTab cavlc;
+    DfTab dftab;
+    int qconst[6];                                  /* this frame's decision constants: lambda_mv, lambda_q4, skip_thr, skip_thr_i4, lambda_i4, lambda_i16 */
     uint8_t nzctx[12];
     uint16_t qdat[2][42];                           /* this frame's quantizer tables, copied from the task */
     alignas(16) uint8_t win[WIN_W*WIN_STRIDE + 16];  /* reference luma window around the current macroblock */
@@ -864,25 +867,32 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
 /* H:5535-5637 df_strength + edge masking of H:5653-5661 -> L.bs */
 DEV void df_strength(RowLds &L, const MbCtx &m, int top_type)
 {
-    uint32_t flag = L.df_nzflag;
-    if (m.type < 5)
+    /* one lane per 4x4 edge segment: lanes 0..15 the vertical edges (bs[4x + y]), 16..31 the horizontal ones (bs[16 + 4y + x]) */
+    const uint32_t flag = L.df_nzflag;
+    const int intra = m.type >= 5;
+    const int strong_l = intra || (m.x && L.left_type >= 5), strong_t = intra || top_type >= 5;
+    WAVE_FOR(l)
     {
-        int k = 0;
-        for (int y = 0; y < 4; y++, flag >>= 1, k++)
-            for (int x = 0; x < 4; x++, flag >>= 1, k++)
+        if (l < 32)
+        {
+            const int dir = l >> 4, i = l & 15;
+            const int x = dir ? (i & 3) : (i >> 2), y = dir ? (i >> 2) : (i & 3), k = 5*y + x;
+            int s;
+            if (intra) s = i < 4 ? 0 : 3;
+            else
             {
-                const mv32 a = L.df_mv[k + 4], c = L.df_mv[k + 5], t = L.df_mv[k];
-                L.bs[4*x + y] = (uint8_t)((flag & (3 << 4)) ? 2 : (iabs(mvx(a) - mvx(c)) > 3 || iabs(mvy(a) - mvy(c)) > 3) ? 1 : 0);
-                L.bs[16 + 4*y + x] = (uint8_t)((flag & 33) ? 2 : (iabs(mvx(t) - mvx(c)) > 3 || iabs(mvy(t) - mvy(c)) > 3) ? 1 : 0);
+                const uint32_t f = flag >> k;
+                const mv32 c = L.df_mv[k + 5], o = dir ? L.df_mv[k] : L.df_mv[k + 4];
+                s = (f & (dir ? 33u : 0x30u)) ? 2 : (iabs(mvx(o) - mvx(c)) > 3 || iabs(mvy(o) - mvy(c)) > 3) ? 1 : 0;
             }
-    } else
-    {
-        for (int i = 0; i < 16; i++) L.bs[i] = L.bs[16 + i] = (uint8_t)(i < 4 ? 0 : 3);
+            if (i < 4)
+            {
+                if (dir ? strong_t : strong_l) s = 4;
+                if (dir ? !m.y : !m.x) s = 0;
+            }
+            L.bs[l] = (uint8_t)s;
+        }
     }
-    if (m.type >= 5 || (m.x && L.left_type >= 5)) for (int i = 0; i < 4; i++) L.bs[i] = 4;
-    if (m.type >= 5 || top_type >= 5) for (int i = 0; i < 4; i++) L.bs[16 + i] = 4;
-    if (!m.x) for (int i = 0; i < 4; i++) L.bs[i] = 0;
-    if (!m.y) for (int i = 0; i < 4; i++) L.bs[16 + i] = 0;
     wave_sync();
 }
 

@@ -62,6 +62,9 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
         for (int k = l; k < 144; k += 64) L.i4s.lut[k] = k_i4_lut[k/16][k%16];
     }
     cavlc_tab_load(L.cavlc);
+    df_tab_load(L.dftab);
+    L.qconst[0] = k_lambda_mv_q4[T.qp]; L.qconst[1] = k_lambda_q4[T.qp]; L.qconst[2] = k_skip_thr_inter[T.qp];
+    L.qconst[3] = k_skip_thr_i4x4[T.qp]; L.qconst[4] = k_lambda_i4_q4[T.qp]; L.qconst[5] = k_lambda_i16_q4[T.qp];
     for (int i = 0; i < 32; i++) L.prof[i] = 0;
     L.prof_last = 0;
 #if defined(H264E_STAMPS) && !defined(H264E_EMU)
@@ -74,7 +77,7 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
 
 /* neighbour record of the macroblock above -> LDS (h264-lab.h:742-745 contexts, :590-606 deblock state): 16 coherent dword
  * loads of the record (+2 of the record to its right), staged in LDS, then unpacked */
-DEV void load_top(RowLds &L, const h264e_geom_t &G, const GLOBAL_AS h264e_mbbottom_t *above, int x, int have_top)
+DEV void load_top(RowLds &L, const h264e_geom_t &G, const GLOBAL_AS h264e_mbbottom_t *above, const GLOBAL_AS h264e_mbpend_t *pend_above, int x, int have_top)
 {
     if (have_top)
     {
@@ -83,6 +86,7 @@ DEV void load_top(RowLds &L, const h264e_geom_t &G, const GLOBAL_AS h264e_mbbott
             if (l < 16) lds32_store(L.trec + 4*l, cload32((const gu8 *)(above + x) + 4*l));
             else if (l == 16) lds32_store(L.trec + 64, x + 1 < G.nmbx ? cload32((const gu8 *)(above + x + 1)) : 0u);                /* pix[0..3] of the above-right record */
             else if (l == 17) lds32_store(L.trec + 68, x + 1 < G.nmbx ? cload32((const gu8 *)(above + x + 1) + 32) : 0u);           /* its mv[0] */
+            else if (l >= 32 && l < 56) lds32_store(L.ptop + 4*(l - 32), cload32((const gu8 *)(pend_above + x) + 4*(l - 32)));    /* for the deblocking at the end of the step */
         }
         wave_sync();
         WAVE_FOR(l)
@@ -163,12 +167,12 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
     m.cropped = G.cropping && ((x + 1)*16 > G.width || (row + 1)*16 > G.height);
     m.type = 0; m.cost = 0x7FFFFFFF; m.i16_mode = 0; m.used_cand = 0; m.mv_skip_pred = 0; m.nz_mask = 0;
     m.qp = T.qp;
-    m.lambda_mv = uni((int)k_lambda_mv_q4[T.qp]); m.lambda_q4 = uni((int)k_lambda_q4[T.qp]); m.skip_thr = uni((int)k_skip_thr_inter[T.qp]);
-    m.skip_thr_i4 = uni((int)k_skip_thr_i4x4[T.qp]); m.lambda_i4 = uni((int)k_lambda_i4_q4[T.qp]); m.lambda_i16 = uni((int)k_lambda_i16_q4[T.qp]);
+    m.lambda_mv = uni(L.qconst[0]); m.lambda_q4 = uni(L.qconst[1]); m.skip_thr = uni(L.qconst[2]);
+    m.skip_thr_i4 = uni(L.qconst[3]); m.lambda_i4 = uni(L.qconst[4]); m.lambda_i16 = uni(L.qconst[5]);
 
     GLOBAL_AS h264e_mbbottom_t *rowrec = C.bottom + (size_t)row*G.nmbx;
     STAMP(L, 0);
-    load_top(L, G, rowrec - G.nmbx, x, row > 0);
+    load_top(L, G, rowrec - G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, row > 0);
     /* the input macroblock and the reference window are already in LDS (row_prefetch) */
     m.rv.dep = (const GLOBAL_AS int *)T.dep_progress; m.rv.nmbx = G.nmbx; m.rv.nmby = G.nmby;
     m.rv.P = m.ref[0]; m.rv.win = (const lu8 *)L.win; m.rv.has_win = T.slice_type == 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
@@ -234,7 +238,7 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
     const bool direct = T.no_deblock || row == G.nmby - 1;      /* nothing below will filter the bottom lines: they are final now */
     if (!T.no_deblock)
     {
-        df_strength(L, m, L.top_type);
+        { PTIC(); df_strength(L, m, L.top_type); PTOC(L, 15); }
         WAVE_FOR(l)
         {
             if (l < 16) lds32_store(L.ytile + (4 + l)*YT_STRIDE, lds32(L.strip_y + 4*l));
@@ -247,18 +251,18 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
             {
                 int r = (l - 32) >> 2, c = l & 3;
                 uint32_t v = 0;
-                if (row > 0) v = cload32((const gu8 *)(pend_row - G.nmbx)[x].y + 16*r + 4*c);
+                if (row > 0) v = lds32(L.ptop + 16*r + 4*c);
                 lds32_store(L.ytile + r*YT_STRIDE + 4 + 4*c, v);
             } else if (l < 56)
             {
                 int pl = (l >> 2) & 1, r = (l >> 1) & 1, c = l & 1;
                 uint32_t v = 0;
-                if (row > 0) v = cload32((const gu8 *)(pend_row - G.nmbx)[x].c[pl] + 8*r + 4*c);
+                if (row > 0) v = lds32(L.ptop + 64 + 16*pl + 8*r + 4*c);
                 memcpy(L.ctile[pl] + r*CT_STRIDE + 2 + 4*c, &v, 4);
             }
         }
         wave_sync();
-        wave_deblock(L.ytile, L.ctile[0], L.ctile[1], L.bs, T.qp, L.left_qp, L.top_qp);
+        { PTIC(); wave_deblock(L.ytile, L.ctile[0], L.ctile[1], L.bs, T.qp, L.left_qp, L.top_qp, L.dftab); PTOC(L, 30); }
     }
     /* write the macroblock: final lines into the picture, the bottom lines into the pending record */
     WAVE_FOR(l)

@@ -42,7 +42,7 @@ def main():
 
 
         if t[15] or t[30]:
-            print("halfpel3 mismatches: q00 %d  q02 %d  q20 %d  q22 %d" % (t[15], t[30] & 0xfffff, (t[30] >> 20) & 0xfffff, t[30] >> 40))
+            print("inside 'ctx save + deblock + stores': df_strength %.0f  wave_deblock %.0f cycles/MB" % (t[15] / nmb, t[30] / nmb))
         if t[29]:
             print("effective shader clock over the rows' lifetimes: %.0f MHz (cycle counter / 100 MHz wall clock)" % (100.0 * t[28] / t[29]))
         if t[24] or t[25]:
