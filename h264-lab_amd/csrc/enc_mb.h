@@ -425,6 +425,10 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
     const int bx = m.x*16, by = m.y*16;
     int sad, sad_skip = 0x7FFFFFFF, sad_best = 0x7FFFFFFF, cand_cost_best = 0, j = 0, ncand = 0, sad4[4];
     mv32 mv_best = MV_NA;
+    LaneArr cand;                           /* start candidates (H:5360-5386), register resident */
+#ifndef H264E_EMU
+    cand.r = 0;
+#endif
 
     /* H:3877-3890 skip predictor */
     const mv32 mv_pred16 = mvp_get(L, m, 0, 0, 4, 4);
@@ -456,7 +460,8 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
             }
         }
         if (m.T->speed < 1) partition_hints(sad4, prefer);
-        mv_best = L.cand[ncand++] = mvround(mv_skip);
+        mv_best = mvround(mv_skip);
+        cand.set(ncand++, mv_best);
         if (!((mvx(mv_skip) | mvy(mv_skip)) & 3))
         {
             sad_best = sad_skip;
@@ -467,27 +472,25 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
 
     STAMP(L, 3);
     m.used_cand = 1;
-    L.cand[ncand++] = mv_pred16;
-    L.cand[ncand++] = 0;                                                    /* H:3895-3914 */
-    if ((m.avail & AV_L) && L.mv_left[0] != MV_NA) L.cand[ncand++] = L.mv_left[0];
-    if ((m.avail & AV_T) && L.mv_top[0] != MV_NA) L.cand[ncand++] = L.mv_top[0];
-    if ((m.avail & AV_TR) && L.mv_top[4] != MV_NA) L.cand[ncand++] = L.mv_top[4];
-    if (m.x <= 0) L.cand[ncand++] = mvmk(8*4, 0);
-    if (m.y <= 0) L.cand[ncand++] = mvmk(0, 8*4);
+    cand.set(ncand++, mv_pred16);
+    cand.set(ncand++, 0);                                                    /* H:3895-3914 */
+    if ((m.avail & AV_L) && L.mv_left[0] != MV_NA) cand.set(ncand++, L.mv_left[0]);
+    if ((m.avail & AV_T) && L.mv_top[0] != MV_NA) cand.set(ncand++, L.mv_top[0]);
+    if ((m.avail & AV_TR) && L.mv_top[4] != MV_NA) cand.set(ncand++, L.mv_top[4]);
+    if (m.x <= 0) cand.set(ncand++, mvmk(8*4, 0));
+    if (m.y <= 0) cand.set(ncand++, mvmk(0, 8*4));
     {
         const GLOBAL_AS mv32 *clu = m.T->clusters_per_mb ? (const GLOBAL_AS mv32 *)m.T->clusters_per_mb + 2*m.num : (const GLOBAL_AS mv32 *)m.T->clusters;
-        L.cand[ncand++] = clu[0];
-        L.cand[ncand++] = clu[1];
+        cand.set(ncand++, clu[0]);
+        cand.set(ncand++, clu[1]);
     }
     {   /* H:5198-5218 round to full-pel, drop duplicates */
         int k = 1;
-        L.cand[0] = mvround(L.cand[0]);
+        cand.set(0, mvround(cand.get(0)));
         for (int n = 1; n < ncand; n++)
         {
-            mv32 v = mvround(L.cand[n]);
-            int i;
-            for (i = 0; i < k; i++) if (L.cand[i] == v) break;
-            if (i == k) L.cand[k++] = v;
+            const mv32 v = mvround(cand.get(n));
+            if (!cand.has(v, k)) cand.set(k++, v);      /* one compare + ballot instead of a scan of the list */
         }
         ncand = k;
     }
@@ -496,7 +499,7 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
     const rect_t lim = mv_limit(m);
     for (; j < ncand; j++)
     {
-        const mv32 cj = L.cand[j], va = mb_abs(m, cj);
+        const mv32 cj = cand.get(j), va = mb_abs(m, cj);
         if (in_rect(va, lim))
         {
             int c = mv_cost(m, cj, mv_pred16), s4[4];

@@ -153,6 +153,31 @@ DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 #define PTOC(L, id) do { } while (0)
 #endif
 
+/*
+ * A small array of wave-uniform ints indexed by a wave-uniform index, held in ONE vector register (lane i = element i):
+ * v_readlane / v_writelane take a few cycles where an LDS-resident scalar costs a full LDS round trip per access.
+ * Only for the uniform control code (every lane calls get/set with the same arguments).
+ */
+struct LaneArr
+{
+#ifdef H264E_EMU
+    int a[64];
+    int get(int i) const { return a[i]; }
+    void set(int i, int v) { a[i] = v; }
+    int has(int v, int n) const { for (int i = 0; i < n; i++) if (a[i] == v) return 1; return 0; }     /* is v among the first n elements? */
+#else
+    int r;
+    __device__ __forceinline__ int get(int i) const { return __builtin_amdgcn_readlane(r, __builtin_amdgcn_readfirstlane(i)); }
+    __device__ __forceinline__ void set(int i, int v)
+    {
+        /* no clang builtin for v_writelane_b32; the lane select goes through m0 (gfx9 allows one SGPR operand); s_nop: an SGPR
+         * written by a VALU instruction (readfirstlane) needs 4 wait states before it is used as data / lane select here */
+        asm volatile("s_nop 3\n\ts_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(r) : "s"(__builtin_amdgcn_readfirstlane(v)), "s"(__builtin_amdgcn_readfirstlane(i)) : "m0");
+    }
+    __device__ __forceinline__ int has(int v, int n) const { return __ballot((int)threadIdx.x < n && r == __builtin_amdgcn_readfirstlane(v)) != 0; }
+#endif
+};
+
 typedef LDS_AS uint8_t lu8;                           /* a byte in LDS (explicit, so out-of-line functions keep ds_* instructions) */
 typedef GLOBAL_AS uint8_t gu8;                        /* a byte in HBM */
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
