@@ -247,11 +247,22 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
                             if (want & 8) sv[3] = (int)sad4_u8(ref_load4(R.P, cx + 4*c4, cy + r - 1), in4, 0);
                         }, s4);
                     }
-                    bs0 = s4[0]; bs1 = s4[1]; bs2 = s4[2]; bs3 = s4[3];
+                    /* SAD + vector cost of the four neighbours; the four costs are computed in four lanes at once */
+#ifdef H264E_EMU
+                    bs0 = s4[0] + mv_cost(m, mvadd(mv, mvmk(DX(0), DY(0))), mv_pred); bs1 = s4[1] + mv_cost(m, mvadd(mv, mvmk(DX(1), DY(1))), mv_pred);
+                    bs2 = s4[2] + mv_cost(m, mvadd(mv, mvmk(DX(2), DY(2))), mv_pred); bs3 = s4[3] + mv_cost(m, mvadd(mv, mvmk(DX(3), DY(3))), mv_pred);
+#else
+                    {
+                        const int dl = (int)threadIdx.x & 3;
+                        const int cl = mv_cost(m, mvadd(mv, mvmk(DX(dl), DY(dl))), mv_pred);
+                        bs0 = s4[0] + __builtin_amdgcn_readlane(cl, 0); bs1 = s4[1] + __builtin_amdgcn_readlane(cl, 1);
+                        bs2 = s4[2] + __builtin_amdgcn_readlane(cl, 2); bs3 = s4[3] + __builtin_amdgcn_readlane(cl, 3);
+                    }
+#endif
                     have = want;
                     PTOC(L, 16);
                 }
-                cost = (dir == 0 ? bs0 : dir == 1 ? bs1 : dir == 2 ? bs2 : bs3) + mv_cost(m, v, mv_pred);
+                cost = dir == 0 ? bs0 : dir == 1 ? bs1 : dir == 2 ? bs2 : bs3;
                 CSET(cur, dir, (uint32_t)cost);
                 if (cost < min_sad)
                 {
@@ -352,8 +363,16 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
         wave_sync();
         int best = -1;
         mv32 vbest = (mv32)uni(mv);
+#ifdef H264E_EMU
+#define TRY(i, vv) { const mv32 vu = (vv); const int cst = s8[i] + mv_cost(m, vu, mv_pred); if (cst < min_sad) { min_sad = cst; vbest = vu; best = i; } }
+#else
+        /* the seven vector costs in seven lanes (one pass of VALU code instead of seven scalar ones), read back with v_readlane */
+        const int ln = (int)threadIdx.x;
+        const mv32 vln = ln == 0 ? v02 : ln == 1 ? v01 : ln == 2 ? v20 : ln == 3 ? v10 : ln == 4 ? v11 : ln == 5 ? v22 : v12;
+        const int cln = mv_cost(m, vln, mv_pred);
         /* uni(): keeps the scalar bookkeeping below from being merged with the same expressions inside the lane code above */
-#define TRY(i, vv) { const mv32 vu = (mv32)uni(vv); const int cst = s8[i] + mv_cost(m, vu, mv_pred); if (cst < min_sad) { min_sad = cst; vbest = vu; best = i; } }
+#define TRY(i, vv) { const mv32 vu = (mv32)uni(vv); const int cst = s8[i] + __builtin_amdgcn_readlane(cln, i); if (cst < min_sad) { min_sad = cst; vbest = vu; best = i; } }
+#endif
         TRY(0, v02) TRY(1, v01) TRY(2, v20) TRY(3, v10) TRY(4, v11) TRY(5, v22) TRY(6, v12)
 #undef TRY
         const uint8_t *src = best < 0 ? L.p00 : best == 0 ? L.p02 : best == 1 ? L.skip_tmp[0] : best == 2 ? L.p20 : best == 3 ? L.skip_tmp[1] :
