@@ -195,6 +195,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
     px = uni(px); py = uni(py); w = uni(w); h = uni(h);
     const int g = w >> 2, n = g*h;
     PCOUNT(L, 18);
+    PTIC();
     for (;;)
     {
         dir = 0; cloop = 4; dir_prev = -1;
@@ -304,6 +305,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
 #undef DX
 #undef DY
 
+    PTOC(L, 15);
     STAMP(L, 5);
     if (!(m.T->speed < 9 && in_rect(mv, mv_qlimit(m))))
     {

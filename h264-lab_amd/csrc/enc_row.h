@@ -238,7 +238,7 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
     const bool direct = T.no_deblock || row == G.nmby - 1;      /* nothing below will filter the bottom lines: they are final now */
     if (!T.no_deblock)
     {
-        { PTIC(); df_strength(L, m, L.top_type); PTOC(L, 15); }
+        df_strength(L, m, L.top_type);
         WAVE_FOR(l)
         {
             if (l < 16) lds32_store(L.ytile + (4 + l)*YT_STRIDE, lds32(L.strip_y + 4*l));
@@ -262,7 +262,7 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
             }
         }
         wave_sync();
-        { PTIC(); wave_deblock(L.ytile, L.ctile[0], L.ctile[1], L.bs, T.qp, L.left_qp, L.top_qp, L.dftab); PTOC(L, 30); }
+        wave_deblock(L.ytile, L.ctile[0], L.ctile[1], L.bs, T.qp, L.left_qp, L.top_qp, L.dftab);
     }
     /* write the macroblock: final lines into the picture, the bottom lines into the pending record */
     WAVE_FOR(l)

@@ -121,6 +121,20 @@ def test_1080p_streaming_through_misspeculation(P):
     assert fs == sizes and out == want
 
 
+def test_1080p_long_clip_is_invariant(P):
+    """240 frames of the bench clip (about ten abort/relaunch cycles): the stream must not depend on how many frames are
+    in flight per launch, nor change from run to run -- a race in the in-launch hand-offs would show here"""
+    w, h, n, gop = 1920, 1080, 240, 30
+    outs = []
+    for frames_in_flight in (96, 20, 96):
+        ce = P.ClipEncoder(w, h, n, gop=gop, qp=26, max_chains=frames_in_flight)
+        ce.generate_synth()
+        out, fs, st = ce.encode()
+        ce.close()
+        outs.append((hashlib.md5(out).hexdigest(), fs))
+    assert outs[0] == outs[1] == outs[2]
+
+
 @pytest.mark.parametrize("w,h,n", [(3840, 2160, 3), (7680, 4320, 2)])
 def test_4k_8k_match_oracle(P, w, h, n):
     """BASELINE configs[3]/[4] geometry (32 400 / 129 600 macroblocks per frame, 8K is cropped): I + P frames"""

@@ -39,15 +39,13 @@ def main():
     if t[18]:
         print("diamond calls/MB %.2f  scan iterations/call %.1f  SAD batches/call %.2f  cycles/batch %.0f  cycles/diag-probe-phase per call %.0f" %
               (t[18] / nmb, t[19] / t[18], t[17] / t[18], t[16] / max(t[17], 1), t[23] / t[18]))
-
-
-        if t[15] or t[30]:
-            print("inside 'ctx save + deblock + stores': df_strength %.0f  wave_deblock %.0f cycles/MB" % (t[15] / nmb, t[30] / nmb))
-        if t[29]:
-            print("effective shader clock over the rows' lifetimes: %.0f MHz (cycle counter / 100 MHz wall clock)" % (100.0 * t[28] / t[29]))
-        if t[24] or t[25]:
-            print("cycles per macroblock by type: skip %.0f  inter %.0f  intra %.0f;  partition set-up before each diamond call %.0f" %
-                  (t[24] / max(t[20], 1), t[25] / max(t[21], 1), t[26] / max(t[22], 1), t[27] / max(t[18], 1)))
+        if t[15]:
+            print("diamond: entry..end of the full-pel search %.0f cycles per call (incl. batches and the diagonal probe)" % (t[15] / t[18]))
+    if t[29]:
+        print("effective shader clock over the rows' lifetimes: %.0f MHz (cycle counter / 100 MHz wall clock)" % (100.0 * t[28] / t[29]))
+    if t[24] or t[25]:
+        print("cycles per macroblock by type: skip %.0f  inter %.0f  intra %.0f;  partition set-up before each diamond call %.0f" %
+              (t[24] / max(t[20], 1), t[25] / max(t[21], 1), t[26] / max(t[22], 1), t[27] / max(t[18], 1)))
 
 
 if __name__ == "__main__":
