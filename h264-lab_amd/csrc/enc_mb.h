@@ -552,9 +552,9 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
             PTIC();
             rect_t range;
             mv32 mvabs = mb_abs(m, mv_best);
-            set_range(mvabs, range, lim, m.y*64 + py*4);
             const mv32 mvp = mvp_get(L, m, px >> 2, py >> 2, w >> 2, h >> 2);
-            if (t)
+            if (!t) set_range(mvabs, range, lim, m.y*64 + py*4);
+            else
             {
                 mvabs = mvround(mb_abs(m, mvp));
                 set_range(mvabs, range, lim, m.y*64 + py*4);
