@@ -65,8 +65,30 @@ def cpu_baseline(sample_frames=60):
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
         dt = time.time() - t0
         ref_bytes = open(out, "rb").read()
-    return {"value": sample_frames * NMB / dt, "unit": "macroblocks/s", "cores": 1, "kind": kind,
-            "sample": "first %d frames of the same 1080p synth_v1 clip, IPPP GOP %d QP %d, single thread, %.1f s" % (sample_frames, GOP, QP, dt)}, ref_bytes
+        res = {"value": sample_frames * NMB / dt, "unit": "macroblocks/s", "cores": 1, "kind": kind,
+               "sample": "first %d frames of the same 1080p synth_v1 clip, IPPP GOP %d QP %d, single thread, %.1f s" % (sample_frames, GOP, QP, dt)}
+        # the same program on every host core at once: N independent processes, one GOP-aligned chunk of the clip each
+        # (SURVEY.md section 8d (ii)); informational, never allowed to disturb the single-core figure above
+        try:
+            ncpu = max(1, min(len(os.sched_getaffinity(0)), sample_frames // GOP * 8, 16))
+            chunks = []
+            for k in range(ncpu):
+                f = os.path.join(tmp, "chunk%d_%dx%d.yuv" % (k, W, H))
+                with open(f, "wb") as fh:
+                    for t in range(GOP):
+                        lib.synth_v1_frame(buf, W, H, k * GOP + t, 1)
+                        fh.write(bytes(buf))
+                chunks.append(f)
+            t0 = time.time()
+            procs = [subprocess.Popen([cmd[0], "--input", f, "--output", f + ".264", "--qp", str(QP), "--gop", str(GOP)], stdout=subprocess.DEVNULL) for f in chunks]
+            ok = all(p.wait() == 0 for p in procs)
+            dta = time.time() - t0
+            if ok:
+                res["all_cores"] = {"value": ncpu * GOP * NMB / dta, "unit": "macroblocks/s", "cores": ncpu,
+                                    "sample": "%d processes x one %d-frame GOP of the clip each, %.1f s" % (ncpu, GOP, dta)}
+        except Exception as e:  # pragma: no cover
+            res["all_cores"] = {"value": None, "sample": "failed: %r" % (e,)}
+    return res, ref_bytes
 
 
 def main():

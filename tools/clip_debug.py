@@ -1,9 +1,26 @@
-import sys, os, time
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
-os.environ['H264E_DEBUG']='1'
-from __graft_entry__ import _pkg
-P=_pkg()
-n=int(sys.argv[1]) if len(sys.argv)>1 else 600
-ce=P.ClipEncoder(1920,1080,n,gop=30,qp=26); ce.generate_synth()
-t=time.time(); out,fs,st=ce.encode(profile=True); dt=time.time()-t
-print("time %.2f s rounds %d reenc %d launches %d mb_ms %.1f enc_ms %.1f read_ms %.1f asm_ms %.1f"%(dt,st.rounds,st.reencoded_gops,st.kernel_launches,st.mb_kernel_ms,st.encode_ms,st.readback_ms,st.assemble_ms))
+#!/usr/bin/env python3
+"""Streaming clip encoder timing with the per-launch timeline (H264E_DEBUG):  clip_debug.py [frames] [w h] [gop] [qp]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["H264E_DEBUG"] = "1"
+from __graft_entry__ import _pkg  # noqa: E402
+
+P = _pkg()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
+gop = int(sys.argv[4]) if len(sys.argv) > 4 else 30
+qp = int(sys.argv[5]) if len(sys.argv) > 5 else 26
+ce = P.ClipEncoder(w, h, n, gop=gop, qp=qp)
+ce.generate_synth()
+ce.encode()                                     # warm-up (clock ramp, first-touch)
+t = time.time()
+out, fs, st = ce.encode(profile=True)
+dt = time.time() - t
+nmb = ((w + 15) // 16) * ((h + 15) // 16)
+print("time %.2f s rounds %d reenc %d launches %d mb_ms %.1f enc_ms %.1f read_ms %.1f asm_ms %.1f  | %dx%d %d frames: %.2f M MB/s, %.1f fps, %d bytes" %
+      (dt, st.rounds, st.reencoded_gops, st.kernel_launches, st.mb_kernel_ms, st.encode_ms, st.readback_ms, st.assemble_ms, w, h, n, n * nmb / dt / 1e6, n / dt, len(out)))
