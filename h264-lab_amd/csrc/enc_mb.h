@@ -6,7 +6,7 @@
  * ("H:n"): inter_choose_mode (H:5283), me_search_diamond (H:4973), intra_choose_16x16/4x4 (H:4876, H:4723),
  * mb_write (H:4378), df_strength/mb_deblock (H:5535, H:5642).  Layout is ours: neighbour state of the row
  * above comes from per-macroblock records in HBM, the left neighbour lives in LDS, bits go to a per-row
- * buffer that a second kernel splices (skip runs are resolved there).
+ * buffer that the frame's finalizer workgroup splices (skip runs are resolved there).
  */
 #ifndef H264E_ENC_MB_H
 #define H264E_ENC_MB_H
@@ -792,7 +792,7 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
         if (m.T->slice_type != 2)
         {
             if (L.coded_any) bw_ue(b, (uint32_t)L.skip_run);
-            else L.lead_skips = L.skip_run;             /* the splice kernel writes this run: it may extend into earlier rows */
+            else L.lead_skips = L.skip_run;             /* the finalizer writes this run: it may extend into earlier rows */
             L.skip_run = 0;
         }
         L.coded_any = 1;

@@ -1,8 +1,9 @@
 /*
  * h264e_dev.h -- data layout shared by the kernels and their launcher.
  *
- * HBM layout per CHAIN (one chain = one sequential stream of frames; GOPs are independent chains):
- *   rec[2][3]   two reconstructed pictures (ping-pong reference / current), coded size, no guard band:
+ * HBM layout per SLOT ("chain"): plain mode = one sequential stream of frames per slot with two pictures in ping-pong;
+ * stream mode = a ring of slots, frame f of the stream in slot f mod K, each referencing the picture of the slot before it:
+ *   rec[2][3]   two reconstructed pictures (stream mode uses the first), coded size, no guard band:
  *               out-of-picture reference reads clamp coordinates, which equals the reference's
  *               replicated borders (h264-lab.h:2232-2248, 3580-3596)
  *   bottom      one 64-byte record per macroblock: what the row below needs from it
@@ -10,7 +11,7 @@
  *   progress    one counter per macroblock row: macroblocks finished in that row (wavefront hand-off)
  *   rowbits     one bit buffer per macroblock row (MSB-first 32-bit words)
  *   mbrec       per macroblock {mv[0], type, used-candidates} for the mv_clusters validation
- *   arena       finished slice RBSPs, appended by the finalize kernel
+ *   arena       finished slice RBSPs, written by the frame's finalizer workgroup
  */
 #ifndef H264E_DEV_H
 #define H264E_DEV_H

@@ -83,7 +83,7 @@ def test_gop_chain_encoder_matches_oracle(P, name, w, h, n, gop, qp, chains):
 
 
 def test_1080p_full_size_properties(P):
-    """BASELINE configs[2] shape (cropped 1080p, GOP chains).  Oracle-checked prefix + size-independent properties:
+    """BASELINE configs[2] shape (cropped 1080p, streaming clip encoder).  Oracle-checked prefix + size-independent properties:
     chain-count invariance, run-to-run determinism, clip encoder == frame-at-a-time API."""
     w, h, n, gop = 1920, 1080, 12, 4
     ce = P.ClipEncoder(w, h, n, gop=gop, qp=26)

@@ -12,7 +12,7 @@ from __graft_entry__ import _pkg  # noqa: E402
 
 NAMES = {0: "setup", 1: "load top+input", 2: "inter: predictors", 3: "inter: skip test", 4: "inter: candidates", 5: "inter: diamond full-pel",
          6: "inter: sub-pel", 7: "inter: partition loop rest", 8: "intra 16x16", 9: "intra 4x4", 10: "chroma prediction", 11: "mb_write (xform/quant/CAVLC/recon)",
-         12: "ctx save + deblock + stores", 13: "WAIT for row above (poll+acquire)", 14: "publish (release fence)"}
+         12: "ctx save + deblock + stores", 13: "WAIT for row above (poll+acquire)", 14: "publish (drain stores)"}
 
 
 def main():
