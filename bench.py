@@ -98,7 +98,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=FRAMES, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    # used only by tests/test_multirank.py to run the N > 1 path on CPU: gloo instead of RCCL, the lane-loop emulation library
+    # of tests/emu instead of the GPU library, a tiny picture
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
+    ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--size", default="%dx%d" % (W, H), help=argparse.SUPPRESS)
     a = ap.parse_args()
+    w, h = (int(v) for v in a.size.split("x"))
+    nmb = ((w + 15) // 16) * ((h + 15) // 16)
+    on_gpu = a.backend == "nccl"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -107,19 +115,24 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend)
 
     from __graft_entry__ import _pkg
     P = _pkg()
     frames = a.frames
-    enc = P.ClipEncoder(W, H, frames, gop=GOP, qp=QP, speed=0, device=local_rank)
+    kw = {"lib": a.lib} if a.lib else {}
+    enc = P.ClipEncoder(w, h, frames, gop=GOP, qp=QP, speed=0, device=local_rank if on_gpu else 0, **kw)
     enc.generate_synth(0, frames, t0=rank * frames, seed=1)   # every rank its own clip (weak scaling)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         out, sizes, st = enc.encode()
@@ -135,27 +148,34 @@ def main():
     barrier()
     dt = time.time() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    per_rank = None
+    if dist is not None and not on_gpu:         # test hook: which stream did every rank produce?
+        import hashlib
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, hashlib.md5(out).hexdigest())
 
     if rank == 0:
-        total_mb = world * a.steps * frames * NMB
+        total_mb = world * a.steps * frames * nmb
         value = total_mb / dt
         # useful algorithmic bytes of the clip (frames that were encoded again after a mis-speculation count once)
-        alg_bytes = a.steps * NMB * sum((BYTES_P if (f % GOP) else BYTES_I) for f in range(frames))
+        alg_bytes = a.steps * nmb * sum((BYTES_P if (f % GOP) else BYTES_I) for f in range(frames))
         achieved = alg_bytes / (mb_ms * 1e-3) / 1e9 if mb_ms > 0 else 0.0
         line = {
             "metric": "1080p macroblocks/sec", "value": value, "unit": "macroblocks/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "synthetic 1920x1080 YUV420 %d frames IPPP GOP %d QP %d on 1xMI355X per rank (BASELINE configs[2])" % (frames, GOP, QP),
+            "config": {"workload": "synthetic %dx%d YUV420 %d frames IPPP GOP %d QP %d on 1xMI355X per rank (BASELINE configs[2])" % (w, h, frames, GOP, QP),
                        "frames_per_step": frames, "frames_in_flight": st.chains, "fps": world * a.steps * frames / dt,
                        "coded_bytes_per_step": len(out), "relaunches_per_step": st.reencoded_gops},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": _pmc_traffic(), "kernel": "h264e_mb_kernel", "launches": launches, "avg_launch_ms": mb_ms / max(launches, 1),
                          "bytes_per_launch": alg_bytes / max(launches, 1), "splice_kernel_ms_total": splice_ms},
         }
+        if per_rank is not None:
+            line["config"]["per_rank_md5"] = per_rank
         if world == 1 and not a.no_cpu_baseline:
             try:
                 cb, ref_bytes = cpu_baseline()

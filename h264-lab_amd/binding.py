@@ -145,7 +145,7 @@ class Encoder:
 
 
 class ClipEncoder:
-    """Whole-clip encode with GOPs as parallel chains on one GPU (H264E_clip_* extension)."""
+    """Whole-clip streaming encode on one GPU (H264E_clip_* extension): consecutive frames as a temporal wavefront."""
 
     def __init__(self, width, height, nframes, gop=30, qp=26, speed=0, device=0, max_chains=0, lib=None,
                  clusters_in=(0, 0), idr_state=0):
