@@ -82,6 +82,23 @@ def test_gop_chain_encoder_matches_oracle(P, name, w, h, n, gop, qp, chains):
     assert fs == sizes and out == want
 
 
+def test_clip_state_handoff_continues_the_stream(P):
+    """two clips with {mv_clusters, idr parity} handed from the first to the second == one clip: what a host
+    that shards a stream at key frames has to pass along"""
+    w, h, n, gop = 352, 288, 12, 3
+    c = clips.make("pan", w, h, n)
+    want, sizes = oracle_lib.encode_clip(c, w, h, gop=gop, qp=26)
+    a = P.ClipEncoder(w, h, 6, gop=gop, qp=26)
+    a.upload(c[:6])
+    out_a, fs_a, st = a.encode()
+    a.close()
+    b = P.ClipEncoder(w, h, 6, gop=gop, qp=26, clusters_in=(st.mv_clusters_out[0], st.mv_clusters_out[1]), idr_state=st.next_idr_pic_id_state)
+    b.upload(c[6:])
+    out_b, fs_b, _ = b.encode()
+    b.close()
+    assert fs_a + fs_b == sizes and out_a + out_b == want
+
+
 def test_1080p_full_size_properties(P):
     """BASELINE configs[2] shape (cropped 1080p, streaming clip encoder).  Oracle-checked prefix + size-independent properties:
     chain-count invariance, run-to-run determinism, clip encoder == frame-at-a-time API."""
