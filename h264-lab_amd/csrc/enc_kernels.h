@@ -146,12 +146,14 @@ struct RefView
     Plane P; const lu8 *win; int has_win, wx0, wy0;
     const GLOBAL_AS int *dep;   /* progress counters of the frame being referenced while it is still being encoded (temporal wavefront) */
     int nmbx, nmby;
+    int vw, vh;                 /* valid columns / rows of the window (h264e_dev.h: wide 64 x 64, narrow 53 x 52) */
+    int *far;                   /* LDS counter of accesses that had to leave the window */
 };
 
 /* wave-uniform: does the sample rectangle [x0,x1] x [y0,y1] lie inside the window? */
 DEV bool rv_inside(const RefView &V, int x0, int y0, int x1, int y1)
 {
-    return V.has_win && x0 >= V.wx0 && y0 >= V.wy0 && x1 < V.wx0 + WIN_W && y1 < V.wy0 + WIN_W;
+    return V.has_win && x0 >= V.wx0 && y0 >= V.wy0 && x1 < V.wx0 + V.vw && y1 < V.wy0 + V.vh;
 }
 DEV const lu8 *rv_ptr(const RefView &V, int x, int y) { return V.win + (y - V.wy0)*WIN_STRIDE + (x - V.wx0); }
 
@@ -164,6 +166,7 @@ DEV const lu8 *rv_ptr(const RefView &V, int x, int y) { return V.win + (y - V.wy
  */
 DEV void rv_wait_rect(const RefView &V, int x1, int y1)
 {
+    if (V.far) *V.far += 1;
 #ifndef H264E_EMU
     if (!V.dep) return;
     const int X = imin(imax(x1, 0), V.P.w - 1) >> 4, Y = imin(imax(y1, 0), V.P.h - 1) >> 4;

@@ -31,6 +31,7 @@ struct RowLds
     alignas(4) uint8_t brec[64];                    /* record of this macroblock for the row below, assembled here */
     BitW bw;
     int skip_run, lead_skips, coded_any;
+    int far_reads;                                  /* reference accesses of this row that left the valid window */
     unsigned long long prof[32], prof_last, prof_c0, prof_w0;
 
     /* ---- per macroblock */

@@ -26,6 +26,7 @@ struct ChainG
     uint32_t arena_cap;
     GLOBAL_AS uint32_t *cursor;
     GLOBAL_AS h264e_frameout_t *fout;
+    GLOBAL_AS int *far_reads;
     unsigned long long *prof;
 };
 DEV ChainG chain_view(const h264e_chain_dev_t &C)
@@ -34,7 +35,7 @@ DEV ChainG chain_view(const h264e_chain_dev_t &C)
     g.bottom = (GLOBAL_AS h264e_mbbottom_t *)C.bottom; g.pend = (GLOBAL_AS h264e_mbpend_t *)C.pend; g.progress = (GLOBAL_AS int *)C.progress;
     g.rowbits = (GLOBAL_AS uint32_t *)C.rowbits; g.rowmeta = (GLOBAL_AS h264e_rowmeta_t *)C.rowmeta;
     g.mbrec = (GLOBAL_AS h264e_mbrec_t *)C.mbrec; g.arena = (GLOBAL_AS uint8_t *)C.arena; g.arena_cap = C.arena_cap;
-    g.cursor = (GLOBAL_AS uint32_t *)C.cursor; g.fout = (GLOBAL_AS h264e_frameout_t *)C.fout; g.prof = C.prof;
+    g.cursor = (GLOBAL_AS uint32_t *)C.cursor; g.fout = (GLOBAL_AS h264e_frameout_t *)C.fout; g.far_reads = (GLOBAL_AS int *)C.far_reads; g.prof = C.prof;
     return g;
 }
 
@@ -55,7 +56,7 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
     L.bw.acc = 0; L.bw.nacc = 0; L.bw.pos = 0; L.bw.overflow = 0;
     L.bw.cap = (uint32_t)G.row_words;
     L.bw.buf = C.rowbits + (size_t)row*G.row_words;
-    L.skip_run = 0; L.lead_skips = 0; L.coded_any = 0;
+    L.skip_run = 0; L.lead_skips = 0; L.coded_any = 0; L.far_reads = 0;
     WAVE_FOR(l)
     {
         for (int k = l; k < 84; k += 64) L.qdat[k/42][k%42] = T.qdat[k/42][k%42];
@@ -151,7 +152,8 @@ DEV void row_prefetch(RowLds &L, const h264e_geom_t &G, const h264e_frame_task_t
     }
 }
 
-DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, int row, int x)
+/* NARROW: compile-time choice of the reference-window geometry (h264e_dev.h) */
+template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, int row, int x)
 {
     MbCtx m;
     PTIC();
@@ -176,6 +178,7 @@ DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e
     /* the input macroblock and the reference window are already in LDS (row_prefetch) */
     m.rv.dep = (const GLOBAL_AS int *)T.dep_progress; m.rv.nmbx = G.nmbx; m.rv.nmby = G.nmby;
     m.rv.P = m.ref[0]; m.rv.win = (const lu8 *)L.win; m.rv.has_win = T.slice_type == 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
+    m.rv.vw = NARROW ? H264E_NARROW_VW : WIN_W; m.rv.vh = NARROW ? H264E_NARROW_VH : WIN_W; m.rv.far = &L.far_reads;
     STAMP(L, 1);
 
     BitW bw = L.bw;
@@ -357,6 +360,11 @@ DEV void row_end(RowLds &L, const h264e_geom_t &G, const ChainG &C, int row)
     gu8 *M = (gu8 *)(C.rowmeta + row);       /* {nbits, lead_skips, trail_skips, overflow}: read by the finalizer workgroup */
     if (wave_lane() == 0)
     {
+#ifdef H264E_EMU
+        *C.far_reads += L.far_reads;
+#else
+        if (L.far_reads) __hip_atomic_fetch_add(C.far_reads, L.far_reads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         cstore32(M, nbits);
         cstore32(M + 4, (uint32_t)(L.coded_any ? L.lead_skips : G.nmbx));
         cstore32(M + 8, (uint32_t)(L.coded_any ? L.skip_run : 0));
@@ -488,6 +496,12 @@ DEV void finalize_frame(const h264e_geom_t &G, const ChainG &C, const h264e_fram
     F.all_skipped = all_skipped;
     F.clusters_moved = moved;
     F.overflow = overflow | s.overflow;
+#ifdef H264E_EMU
+    F.far_reads = *C.far_reads; *C.far_reads = 0;
+#else
+    F.far_reads = __hip_atomic_load(C.far_reads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave_lane() == 0) __hip_atomic_store(C.far_reads, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     *C.cursor = start + ((nbytes + 3u) & ~3u);
     stepflags[0] = moved;
     stepflags[1] = overflow | s.overflow;

@@ -27,6 +27,16 @@
 #define H264E_DEP_ROWS 2
 #define H264E_DEP_COLS 3
 #define H264E_FRAME_LAG (2*H264E_DEP_ROWS + H264E_DEP_COLS)    /* macroblock steps between consecutive frames' starts */
+/* Narrow mode: only the part of the window that ends at local sample (12,11) of reference macroblock (x+1, row+1) counts as
+ * valid (53 columns x 52 rows: 24 samples of reach to the left / up, 12 / 11 to the right / down); those samples are final
+ * once row+1 of the reference frame has published x+2 macroblocks (the pending bottom lines 12..15 are not needed), so
+ * consecutive frames start 4 steps apart.  Vectors that reach further right / down take the HBM path with its dynamic
+ * wait; the host falls back to the wide geometry when a clip does that often (h264e_host.c). */
+#define H264E_NARROW_VW 53
+#define H264E_NARROW_VH 52
+#define H264E_NARROW_DEP_ROWS 1
+#define H264E_NARROW_DEP_COLS 2
+#define H264E_NARROW_FRAME_LAG (2*H264E_NARROW_DEP_ROWS + H264E_NARROW_DEP_COLS)
 
 typedef int32_t mv32;                   /* packed (y << 16) | (x & 0xffff), quarter-pel */
 
@@ -84,7 +94,8 @@ typedef struct
     int32_t all_skipped;
     int32_t clusters_moved;             /* some macroblock's update would change the speculated mv_clusters state */
     int32_t overflow;
-    int32_t pad[3];
+    int32_t far_reads;                  /* reference accesses outside the valid window (HBM path) */
+    int32_t pad[2];
 } h264e_frameout_t;
 
 /* per-job result record in HOST (pinned, device-mapped) memory: lets the host consume frames while the launch runs */
@@ -92,7 +103,8 @@ typedef struct
 {
     uint32_t nbytes;
     int32_t all_skipped, clusters_moved, overflow;
-    int32_t pad[3];
+    int32_t far_reads;
+    int32_t pad[2];
     int32_t done;                       /* written last: launch id when the job's results are complete, -launch id when it was aborted */
 } h264e_hostdone_t;
 
@@ -109,6 +121,7 @@ typedef struct
     uint32_t arena_cap;
     uint32_t *cursor;
     h264e_frameout_t *fout;             /* [frame slots] */
+    int *far_reads;                     /* counter of the frame being encoded (rows add, the finalizer reads and clears) */
     unsigned long long *prof;           /* [32] phase cycle sums, written only by the -DH264E_STAMPS diagnostic build */
 } h264e_chain_dev_t;
 
@@ -128,6 +141,7 @@ typedef struct
     const int *dep_progress;            /* progress counters of the job that builds `ref` in the SAME launch, or NULL when ref is complete */
     int frame_slot;
     int first_row;                      /* macroblock rows above it are kept from the previous encode of this frame */
+    int narrow;                         /* reference-window geometry the launch was made for (all jobs of a launch agree) */
     int hdr_nbits;                      /* NAL header byte + slice header, MSB-aligned at bit hdr_nbits-1 */
     uint64_t hdr_bits;
     mv32 clusters[2];                   /* speculated mv_clusters state for every macroblock of the frame ... */

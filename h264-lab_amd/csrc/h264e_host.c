@@ -775,6 +775,11 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
     uint8_t *rbsp = (uint8_t *)malloc(rbsp_cap);      /* unused by the streaming path, kept for the size check */
     int32_t state[2] = { c->par.mv_clusters_in[0], c->par.mv_clusters_in[1] };
     int first_row = 0;                      /* the frame that is encoded again restarts at the first divergent macroblock row */
+    /* reference-window geometry (h264e_dev.h): narrow = consecutive frames 4 macroblock steps apart, as long as vectors
+     * rarely reach more than 12 samples right / down of their macroblock; wide (7 steps) for the rest of the clip otherwise */
+    /* large pictures already fill the GPU's resident workgroups with the wide geometry: the narrow one only pays below ~12k macroblocks */
+    int narrow = (getenv("H264E_WIDE_WINDOW") || nmb > 12000) ? 0 : 1;
+    long long far_reads = 0;
     int32_t after[2] = { 0, 0 };            /* after a failed validation: predicted state behind the frame that is encoded again */
     int have_after = 0;
     uint16_t qdat_i[2][42], qdat_p[2][42];
@@ -814,6 +819,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             t->mv_clusters[1] = used[i][1] = (i && have_after) ? after[1] : state[1];
             t->mv_clusters_per_mb = (i == 0) ? first_arr : NULL;
             t->first_row = (i == 0 && first_arr) ? first_row : 0;
+            t->narrow_window = narrow;
         }
         stats.rounds++;
         have_after = 0;
@@ -841,7 +847,8 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
                 goto done;
             }
             t_last = now_ms();
-            if (i == 0) t_first = t_last;
+            if (i == 0) { t_first = t_last; far_reads = 0; }
+            far_reads += r1.far_reads;
             if (r1.overflow) { snprintf(g_host_err, sizeof(g_host_err), "bit buffer overflow (frame %d)", f); (void)h264e_hip_stream_abort(c->pool); (void)h264e_hip_sync(c->pool); goto done; }
             if (per_mb || r1.clusters_moved || used[i][0] != state[0] || used[i][1] != state[1])
             {
@@ -881,9 +888,11 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
         if (h264e_hip_sync(c->pool)) goto done;         /* the launch has drained (immediately after an abort) */
         stats.encode_ms += now_ms() - t0;
         n += nvalid;
+        /* more than one macroblock in eight left the narrow window: the wide one pays from here on */
+        if (narrow && nvalid > 0 && far_reads > (long long)nvalid*nmb/8) narrow = 0;
         if (getenv("H264E_DEBUG"))
-            fprintf(stderr, "clip launch %d (first row %d): %d frames in flight, %d valid, next %d; first frame after %.2f ms, then %.3f ms/frame, drained %.2f ms after the last\n",
-                    stats.rounds, tasks[0].first_row, F, nvalid, n, t_first - t_submit, nvalid > 1 ? (t_last - t_first)/(nvalid - 1 + (nvalid < F)) : 0.0, now_ms() - t_last);
+            fprintf(stderr, "clip launch %d (first row %d, %s window, %lld far reads): %d frames in flight, %d valid, next %d; first frame after %.2f ms, then %.3f ms/frame, drained %.2f ms after the last\n",
+                    stats.rounds, tasks[0].first_row, tasks[0].narrow_window ? "narrow" : "wide", far_reads, F, nvalid, n, t_first - t_submit, nvalid > 1 ? (t_last - t_first)/(nvalid - 1 + (nvalid < F)) : 0.0, now_ms() - t_last);
     }
     stats.mv_clusters_out[0] = state[0]; stats.mv_clusters_out[1] = state[1];
     stats.next_idr_pic_id_state = idr_state ^ (((c->nframes + G - 1)/G) & 1);

@@ -56,6 +56,7 @@ DEV int poll_progress(const GLOBAL_AS int *flag, int need, int &seen)
  * Every workgroup only ever waits for workgroups with a lower index (rows above; rows of the reference frame's job;
  * rows of the own job for the finalizer).
  */
+template <bool NARROW>
 __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h264e_chain_dev_t *chains,
                                                          const h264e_frame_task_t *tasks, const uint32_t *order, int *errflag, int *stepflags)
 {
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
                 const GLOBAL_AS h264e_frameout_t &F = C.fout[T.frame_slot];
                 GLOBAL_AS h264e_hostdone_t *hd = (GLOBAL_AS h264e_hostdone_t *)T.host_done;
                 hd->nbytes = F.nbytes; hd->all_skipped = F.all_skipped;
-                hd->clusters_moved = F.clusters_moved; hd->overflow = F.overflow;
+                hd->clusters_moved = F.clusters_moved; hd->overflow = F.overflow; hd->far_reads = F.far_reads;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                 /* system scope: the host reads these */
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(&hd->done, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -112,12 +113,13 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
     if (row < T.first_row) return;          /* kept from the previous encode of this frame (its counter already says complete) */
     row_begin(L, G, C, T, row);
     int seen = 0, seen_dep = 0;
-    const int dep_row = imin(row + H264E_DEP_ROWS, G.nmby - 1);
+    constexpr int DEP_ROWS = NARROW ? H264E_NARROW_DEP_ROWS : H264E_DEP_ROWS, DEP_COLS = NARROW ? H264E_NARROW_DEP_COLS : H264E_DEP_COLS;
+    const int dep_row = imin(row + DEP_ROWS, G.nmby - 1);
     for (int x = 0; x < G.nmbx; x++)
     {
         /* consumer: relaxed sc1 polls, then sc1 loads of everything handed over */
         const int need = row > 0 ? imin(x + 2, G.nmbx) : 0;
-        const int need_dep = T.dep_progress ? imin(x + H264E_DEP_COLS, G.nmbx) : 0;     /* temporal wavefront: h264e_dev.h */
+        const int need_dep = T.dep_progress ? imin(x + DEP_COLS, G.nmbx) : 0;     /* temporal wavefront: h264e_dev.h */
         int st = 0;
         /* the abort word lives in host memory (one PCIe read): look at it every 8th macroblock only */
         if ((x & 7) == 0 && T.abort_word && uni(__hip_atomic_load((const GLOBAL_AS int *)T.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == T.launch_id) st = -2;
@@ -145,7 +147,7 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
             return;
         }
         STAMP(L, 13);
-        row_step(L, G, C, T, row, x);
+        row_step<NARROW>(L, G, C, T, row, x);
         /* producer: every handed-off byte was stored write-through (sc1, wave.h cstore*): drain them, then the counter --
          * no agent-scope release (L2 write-back) needed */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -245,7 +247,7 @@ struct h264e_hip_pool
     h264e_frame_task_t *tasks_dev;       /* ring of TASK_RING task arrays */
     int *progress_all;
     int *errflag;
-    uint32_t *order;                     /* [nchains*(nmby+1)] (job << 16) | row in dispatch order */
+    uint32_t *order;                     /* [2][nchains*(nmby+1)] (job << 16) | row in dispatch order: wide / narrow frame lag */
     int *stepflags;                      /* [nchains][2]: {clusters_moved, overflow} of the last step, one read per step */
     /* streaming: per chain slot, host-mapped result buffers the finalizer workgroups fill while the launch runs */
     h264e_hostdone_t *host_done;         /* [nchains] */
@@ -357,7 +359,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         p->progress_all = (int *)carve(sizeof(int)*(size_t)nchains*G.nmby, 256);
         p->errflag = (int *)carve(sizeof(int), 256);
         p->stepflags = (int *)carve(sizeof(int)*2*(size_t)nchains, 256);
-        p->order = (uint32_t *)carve(sizeof(uint32_t)*(size_t)nchains*(G.nmby + 1), 256);
+        p->order = (uint32_t *)carve(sizeof(uint32_t)*2*(size_t)nchains*(G.nmby + 1), 256);
         p->host_done = (h264e_hostdone_t *)hcarve(sizeof(h264e_hostdone_t)*(size_t)nchains);
         p->abort_word = (int *)hcarve(64);
         for (int c = 0; c < nchains; c++)
@@ -381,6 +383,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
             C.cursor = (uint32_t *)carve(16, 256);
             C.fout = (h264e_frameout_t *)carve(sizeof(h264e_frameout_t)*(size_t)slots, 256);
             C.prof = (unsigned long long *)carve(sizeof(unsigned long long)*32, 256);
+            C.far_reads = (int *)carve(16, 256);
             p->clu_dev[c] = (int32_t *)carve(sizeof(int32_t)*2*(size_t)G.nmb, 256);      /* per-macroblock mv_clusters array of a re-encode */
             if (slots == 1)        /* streaming pools keep one result per chain slot: give each a host-mapped mirror */
             {
@@ -412,18 +415,22 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     {
         /* dispatch order: (job, row) sorted by the step at which the row can start when consecutive jobs are consecutive
          * frames of one stream; every workgroup still only waits for workgroups that precede it in this order */
-        const int rows = G.nmby + 1, total = nchains*rows, maxkey = H264E_FRAME_LAG*(nchains - 1) + 2*(rows - 1);
-        uint32_t *ord = (uint32_t *)malloc(sizeof(uint32_t)*(size_t)total);
+        const int rows = G.nmby + 1, total = nchains*rows;
+        uint32_t *ord = (uint32_t *)malloc(sizeof(uint32_t)*2*(size_t)total);
         int n = 0;
         if (!ord) { h264e_hip_pool_destroy(p); FAIL("out of host memory"); }
-        for (int key = 0; key <= maxkey; key++)
-            for (int job = 0; job < nchains; job++)
-            {
-                const int r2 = key - H264E_FRAME_LAG*job;
-                if (r2 < 0 || (r2 & 1) || (r2 >> 1) >= rows) continue;
-                ord[n++] = ((uint32_t)job << 16) | (uint32_t)(r2 >> 1);
-            }
-        const hipError_t e = (n == total) ? hipMemcpy(p->order, ord, sizeof(uint32_t)*(size_t)total, hipMemcpyHostToDevice) : hipErrorUnknown;
+        for (int mode = 0; mode < 2; mode++)
+        {
+            const int lag = mode ? H264E_NARROW_FRAME_LAG : H264E_FRAME_LAG, maxkey = lag*(nchains - 1) + 2*(rows - 1);
+            for (int key = 0; key <= maxkey; key++)
+                for (int job = 0; job < nchains; job++)
+                {
+                    const int r2 = key - lag*job;
+                    if (r2 < 0 || (r2 & 1) || (r2 >> 1) >= rows) continue;
+                    ord[n++] = ((uint32_t)job << 16) | (uint32_t)(r2 >> 1);
+                }
+        }
+        const hipError_t e = (n == 2*total) ? hipMemcpy(p->order, ord, sizeof(uint32_t)*2*(size_t)total, hipMemcpyHostToDevice) : hipErrorUnknown;
         free(ord);
         if (e != hipSuccess) { h264e_hip_pool_destroy(p); FAIL("dispatch order upload failed"); }
     }
@@ -514,7 +521,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     if (p->pending >= TASK_RING - 1 && h264e_hip_sync(p)) return -1;
     h264e_frame_task_t *host = (h264e_frame_task_t *)calloc((size_t)p->nchains, sizeof(h264e_frame_task_t));
     if (!host) FAIL("out of host memory");
-    int any = 0;
+    int any = 0, any_narrow = 0, any_wide = 0;
     const int launch_id = ++p->launch_counter;
     for (int c = 0; c < p->nchains; c++)
     {
@@ -570,6 +577,9 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         }
         d.frame_slot = t.frame_slot;
         d.first_row = (t.stream_mode && t.first_row > 0 && t.first_row < G.nmby) ? t.first_row : 0;
+        d.narrow = t.stream_mode && t.narrow_window;
+        any_narrow |= d.narrow;
+        any_wide |= !d.narrow;
         d.hdr_nbits = t.hdr_nbits; d.hdr_bits = t.hdr_bits;
         d.clusters[0] = t.mv_clusters[0]; d.clusters[1] = t.mv_clusters[1];
         d.clusters_per_mb = 0;
@@ -593,6 +603,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         d.launch_id = launch_id;
     }
     if (!any) { free(host); return 0; }
+    if (any_narrow && any_wide) { free(host); FAIL("submit: the jobs of one launch must agree on narrow_window"); }
     h264e_frame_task_t *slot = p->tasks_dev + (size_t)p->ring_pos*p->nchains;
     p->ring_pos = (p->ring_pos + 1) % TASK_RING;
     p->pending++;
@@ -608,7 +619,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         {
             RowLds *L = (RowLds *)calloc(1, sizeof(RowLds));
             row_begin(*L, G, C, T, row);
-            for (int x = 0; x < G.nmbx; x++) { row_prefetch(*L, G, T, row, x); row_step(*L, G, C, T, row, x); }
+            for (int x = 0; x < G.nmbx; x++) { row_prefetch(*L, G, T, row, x); if (T.narrow) row_step<true>(*L, G, C, T, row, x); else row_step<false>(*L, G, C, T, row, x); }
             row_end(*L, G, C, row);
             free(L);
         }
@@ -618,7 +629,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             export_frame(G, C, T);
             const h264e_frameout_t &F = C.fout[T.frame_slot];
             T.host_done->nbytes = F.nbytes; T.host_done->all_skipped = F.all_skipped;
-            T.host_done->clusters_moved = F.clusters_moved; T.host_done->overflow = F.overflow;
+            T.host_done->clusters_moved = F.clusters_moved; T.host_done->overflow = F.overflow; T.host_done->far_reads = F.far_reads;
             T.host_done->done = T.launch_id;
         }
     }
@@ -642,8 +653,12 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     if (e != hipSuccess) FAIL("progress reset: %s", hipGetErrorString(e));
     const int pe = p->ev_pending;
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][0], p->stream));
-    hipLaunchKernelGGL(h264e_mb_kernel, dim3((unsigned)(p->nchains*(G.nmby + 1))), dim3(64), 0, p->stream,
-                       G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, (const uint32_t *)p->order, p->errflag, p->stepflags);
+    if (any_narrow)
+        hipLaunchKernelGGL(h264e_mb_kernel<true>, dim3((unsigned)(p->nchains*(G.nmby + 1))), dim3(64), 0, p->stream,
+                           G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, (const uint32_t *)p->order + (size_t)p->nchains*(G.nmby + 1), p->errflag, p->stepflags);
+    else
+        hipLaunchKernelGGL(h264e_mb_kernel<false>, dim3((unsigned)(p->nchains*(G.nmby + 1))), dim3(64), 0, p->stream,
+                           G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, (const uint32_t *)p->order, p->errflag, p->stepflags);
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][1], p->stream));
     HIPCHK(hipGetLastError());
     if (p->profile)
@@ -677,7 +692,7 @@ extern "C" int h264e_hip_stream_done(h264e_hip_pool_t *p, int slot, h264e_hip_re
     if (v == -p->slot_launch[slot]) return 2;               /* the job was aborted */
     if (v != p->slot_launch[slot]) return 0;                /* not yet */
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    if (res) { res->nbytes = d->nbytes; res->all_skipped = d->all_skipped; res->clusters_moved = d->clusters_moved; res->overflow = d->overflow; }
+    if (res) { res->nbytes = d->nbytes; res->all_skipped = d->all_skipped; res->clusters_moved = d->clusters_moved; res->overflow = d->overflow; res->far_reads = d->far_reads; }
     return 1;
 }
 
@@ -722,7 +737,7 @@ extern "C" int h264e_hip_result(h264e_hip_pool_t *p, int chain, int slot, h264e_
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipMemcpy(&f, p->chains_host[chain].fout + slot, sizeof(f), hipMemcpyDeviceToHost));
 #endif
-    res->nbytes = f.nbytes; res->all_skipped = f.all_skipped; res->clusters_moved = f.clusters_moved; res->overflow = f.overflow;
+    res->nbytes = f.nbytes; res->all_skipped = f.all_skipped; res->clusters_moved = f.clusters_moved; res->overflow = f.overflow; res->far_reads = f.far_reads;
     return 0;
 }
 

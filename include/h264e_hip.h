@@ -46,6 +46,9 @@ typedef struct
     /* stream mode: encode this frame again from macroblock row first_row; the rows above it (bits, records, picture) are
      * kept from the previous encode of the same frame in the same slot (0 = whole frame) */
     int first_row;
+    /* stream mode: 1 = narrow valid window (53 x 52 samples, consecutive frames 4 macroblock steps apart), 0 = the whole
+     * 64 x 64 window (7 steps apart); see h264e_dev.h.  Same bits either way. */
+    int narrow_window;
 } h264e_hip_task_t;
 
 typedef struct
@@ -54,6 +57,7 @@ typedef struct
     int all_skipped;            /* every macroblock was skipped (rc_frame_end's skip_flag, h264-lab.h:6596) */
     int clusters_moved;         /* the speculated mv_clusters state is not a fixed point of this frame */
     int overflow;               /* a bit buffer overflowed: the result is invalid */
+    int far_reads;              /* reference accesses that left the valid window and took the HBM path (stream mode) */
 } h264e_hip_result_t;
 
 typedef struct { int32_t mv0; int8_t type; uint8_t used_cand; uint8_t pad[2]; } h264e_hip_mbrec_t;

@@ -140,16 +140,22 @@ def test_1080p_streaming_through_misspeculation(P):
 
 def test_1080p_long_clip_is_invariant(P):
     """240 frames of the bench clip (about ten abort/relaunch cycles): the stream must not depend on how many frames are
-    in flight per launch, nor change from run to run -- a race in the in-launch hand-offs would show here"""
+    in flight per launch or on the reference-window geometry, nor change from run to run -- a race in the in-launch
+    hand-offs would show here"""
     w, h, n, gop = 1920, 1080, 240, 30
     outs = []
-    for frames_in_flight in (96, 20, 96):
-        ce = P.ClipEncoder(w, h, n, gop=gop, qp=26, max_chains=frames_in_flight)
-        ce.generate_synth()
-        out, fs, st = ce.encode()
-        ce.close()
+    for frames_in_flight, wide in ((96, 0), (20, 0), (96, 0), (96, 1)):
+        if wide:
+            os.environ["H264E_WIDE_WINDOW"] = "1"       # the 64x64 window / 7-step frame lag instead of 53x52 / 4 steps
+        try:
+            ce = P.ClipEncoder(w, h, n, gop=gop, qp=26, max_chains=frames_in_flight)
+            ce.generate_synth()
+            out, fs, st = ce.encode()
+            ce.close()
+        finally:
+            os.environ.pop("H264E_WIDE_WINDOW", None)
         outs.append((hashlib.md5(out).hexdigest(), fs))
-    assert outs[0] == outs[1] == outs[2]
+    assert outs[0] == outs[1] == outs[2] == outs[3]
 
 
 @pytest.mark.parametrize("w,h,n", [(3840, 2160, 3), (7680, 4320, 2)])
