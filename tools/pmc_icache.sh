@@ -11,6 +11,6 @@ for p in ['a','b']:
     for f in glob.glob('$OUT/'+p+'/*/*_counter_collection.csv'):
         agg=collections.defaultdict(float)
         for r in csv.DictReader(open(f)):
-            if r['Kernel_Name'].startswith('h264e_mb'): agg[r['Counter_Name']]+=float(r['Counter_Value'])
+            if 'h264e_mb' in r['Kernel_Name']: agg[r['Counter_Name']]+=float(r['Counter_Value'])
         for k,v in sorted(agg.items()): print(k,v)
 PY

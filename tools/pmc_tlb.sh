@@ -13,7 +13,7 @@ import csv,glob,collections
 for f in glob.glob('$OUT/r$i/*/*_counter_collection.csv'):
     agg=collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
-        if r['Kernel_Name'].startswith('h264e_mb'): agg[r['Counter_Name']]+=float(r['Counter_Value'])
+        if 'h264e_mb' in r['Kernel_Name']: agg[r['Counter_Name']]+=float(r['Counter_Value'])
     print({k:("%.4g"%v) for k,v in sorted(agg.items())})
 PY
 done
