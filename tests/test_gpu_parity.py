@@ -138,6 +138,20 @@ def test_1080p_streaming_through_misspeculation(P):
     assert fs == sizes and out == want
 
 
+@pytest.mark.parametrize("qp,speed", [(14, 0), (38, 0), (50, 0), (26, 2), (26, 9), (33, 10)])
+def test_1080p_clip_encoder_qp_and_speed(P, qp, speed):
+    """cropped 1080p through the streaming clip encoder across QPs and encode speeds (speed >= 9: no sub-pel search,
+    8/10: no deblocking), against the oracle"""
+    w, h, n = 1920, 1080, 5
+    ce = P.ClipEncoder(w, h, n, gop=30, qp=qp, speed=speed)
+    ce.generate_synth()
+    out, fs, _ = ce.encode()
+    ce.close()
+    c = oracle_lib.synth_c(w, h, n)
+    want, sizes = oracle_lib.encode_clip(c, w, h, gop=30, qp=qp, speed=speed)
+    assert fs == sizes and out == want
+
+
 def test_1080p_long_clip_is_invariant(P):
     """240 frames of the bench clip (about ten abort/relaunch cycles): the stream must not depend on how many frames are
     in flight per launch or on the reference-window geometry, nor change from run to run -- a race in the in-launch
