@@ -712,7 +712,6 @@ static double now_ms(void)
 int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nframes)
 {
     H264E_clip_t *c;
-    int nmby, cap;
     g_host_err[0] = 0;
     if (!out || !par || nframes <= 0 || par->width <= 0 || par->height <= 0 || ((par->width | par->height) & 1) || par->gop < 0) return -1;
     c = (H264E_clip_t *)calloc(1, sizeof(*c));
@@ -724,8 +723,12 @@ int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nfram
     c->gop_len = par->gop ? par->gop : nframes;
     /* ring of picture / result slots = frames per launch + 1.  Not bounded by residency: workgroups only wait for lower
      * block indices, so a launch larger than the GPU simply streams through it in order. */
-    (void)nmby; (void)cap;
-    c->ring = par->max_chains > 0 ? par->max_chains + 1 : 97;
+    /* default: 96 frames per launch at 1080p and above; small pictures have short pipelines and cheap slots, so they get
+     * proportionally more (fewer launch boundaries), up to 1024 */
+    {
+        const int nmb = c->seq.nmb;
+        c->ring = par->max_chains > 0 ? par->max_chains + 1 : imax(97, imin(1025, 97*8160/imax(nmb, 1)));
+    }
     if (getenv("H264E_RING")) c->ring = atoi(getenv("H264E_RING"));       /* experiments */
     c->ring = imax(2, imin(c->ring, nframes + 1));
     if (h264e_hip_pool_create(&c->pool, par->device, par->width, par->height, c->ring, nframes, 1))
