@@ -267,19 +267,23 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
         wave_sync();
         wave_deblock(L.ytile, L.ctile[0], L.ctile[1], L.bs, T.qp, L.left_qp, L.top_qp, L.dftab);
     }
-    /* write the macroblock: final lines into the picture, the bottom lines into the pending record */
+    /* write the macroblock: final lines into the picture, the bottom lines into the pending record; 8 bytes per lane (every
+     * store is one write-through fabric request, whatever its width) */
     WAVE_FOR(l)
     {
-        int r = l >> 2, c = l & 3;
-        uint32_t v = lds32(ty + YT_STRIDE*r + 4*c);
-        if (r < 12 || direct) cstore32(dy + (size_t)r*W + 4*c, v);
-        else cstore32((gu8 *)pend_row[x].y + 16*(r - 12) + 4*c, v);
         if (l < 32)
         {
-            int pl = l >> 4, rr = (l >> 1) & 7, g = l & 1;
-            uint32_t u = lds32((pl ? tc1 : tc0) + CT_STRIDE*rr + 4*g);
-            if (rr < 6 || direct) cstore32((pl ? dv : du) + (size_t)rr*Wc + 4*g, u);
-            else cstore32((gu8 *)pend_row[x].c[pl] + 8*(rr - 6) + 4*g, u);
+            const int r = l >> 1, hf = l & 1;
+            const uint64_t v = (uint64_t)lds32(ty + YT_STRIDE*r + 8*hf) | ((uint64_t)lds32(ty + YT_STRIDE*r + 8*hf + 4) << 32);
+            if (r < 12 || direct) cstore64(dy + (size_t)r*W + 8*hf, v);
+            else cstore64((gu8 *)pend_row[x].y + 16*(r - 12) + 8*hf, v);
+        } else if (l < 48)
+        {
+            const int pl = (l - 32) >> 3, rr = l & 7;
+            const uint8_t *t = (pl ? tc1 : tc0) + CT_STRIDE*rr;
+            const uint64_t u = (uint64_t)lds32(t) | ((uint64_t)lds32(t + 4) << 32);
+            if (rr < 6 || direct) cstore64((pl ? dv : du) + (size_t)rr*Wc, u);
+            else cstore64((gu8 *)pend_row[x].c[pl] + 8*(rr - 6), u);
         }
     }
     if (!T.no_deblock)
@@ -296,10 +300,16 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
                     if (l < 12 || direct) cstore32(dy + (size_t)l*W - 4, v);
                     else cstore32((gu8 *)pend_row[x - 1].y + 16*(l - 12) + 12, v);
                 }
+            } else if (l < 24)
+            {
+                int r = (l - 16) >> 1, hf = l & 1;                          /* tile rows 0..3 = picture rows -4..-1 */
+                if (row > 0)
+                {
+                    const uint8_t *t = L.ytile + r*YT_STRIDE + 4 + 8*hf;
+                    cstore64(dy - (size_t)(4 - r)*W + 8*hf, (uint64_t)lds32(t) | ((uint64_t)lds32(t + 4) << 32));
+                }
             } else if (l < 32)
             {
-                int r = (l - 16) >> 2, c = l & 3;                           /* tile rows 0..3 = picture rows -4..-1 */
-                if (row > 0) { uint32_t v = lds32(L.ytile + r*YT_STRIDE + 4 + 4*c); cstore32(dy - (size_t)(4 - r)*W + 4*c, v); }
             } else if (l < 48)
             {
                 int pl = (l - 32) >> 3, i = (l - 32) & 7;
@@ -311,10 +321,15 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
                     if (i < 6 || direct) cstore32((pl ? dv : du) + (size_t)i*Wc - 4, v);
                     else cstore32((gu8 *)pend_row[x - 1].c[pl] + 8*(i - 6) + 4, v);
                 }
-            } else if (l < 56)
+            } else if (l < 52)
             {
-                int pl = (l - 48) >> 2, r = (l >> 1) & 1, c = l & 1;       /* tile rows 0..1 = picture rows -2..-1 */
-                if (row > 0) { uint32_t v; memcpy(&v, L.ctile[pl] + r*CT_STRIDE + 2 + 4*c, 4); cstore32((pl ? dv : du) - (size_t)(2 - r)*Wc + 4*c, v); }
+                int pl = (l - 48) >> 1, r = l & 1;                          /* tile rows 0..1 = picture rows -2..-1 */
+                if (row > 0)
+                {
+                    uint32_t lo, hi;
+                    memcpy(&lo, L.ctile[pl] + r*CT_STRIDE + 2, 4); memcpy(&hi, L.ctile[pl] + r*CT_STRIDE + 6, 4);
+                    cstore64((pl ? dv : du) - (size_t)(2 - r)*Wc, (uint64_t)lo | ((uint64_t)hi << 32));
+                }
             }
         }
     }
