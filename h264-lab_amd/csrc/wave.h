@@ -155,7 +155,7 @@ DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
 /*
  * A small array of wave-uniform ints indexed by a wave-uniform index, held in ONE vector register (lane i = element i):
- * v_readlane / v_writelane take a few cycles where an LDS-resident scalar costs a full LDS round trip per access.
+ * v_readlane / a lane-select write take a few cycles where an LDS-resident scalar costs a full LDS round trip per access.
  * Only for the uniform control code (every lane calls get/set with the same arguments).
  */
 struct LaneArr
@@ -168,12 +168,7 @@ struct LaneArr
 #else
     int r;
     __device__ __forceinline__ int get(int i) const { return __builtin_amdgcn_readlane(r, __builtin_amdgcn_readfirstlane(i)); }
-    __device__ __forceinline__ void set(int i, int v)
-    {
-        /* no clang builtin for v_writelane_b32; the lane select goes through m0 (gfx9 allows one SGPR operand); s_nop: an SGPR
-         * written by a VALU instruction (readfirstlane) needs 4 wait states before it is used as data / lane select here */
-        asm volatile("s_nop 3\n\ts_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(r) : "s"(__builtin_amdgcn_readfirstlane(v)), "s"(__builtin_amdgcn_readfirstlane(i)) : "m0");
-    }
+    __device__ __forceinline__ void set(int i, int v) { r = ((int)threadIdx.x == __builtin_amdgcn_readfirstlane(i)) ? __builtin_amdgcn_readfirstlane(v) : r; }    /* compare + select: no v_writelane builtin */
     __device__ __forceinline__ int has(int v, int n) const { return __ballot((int)threadIdx.x < n && r == __builtin_amdgcn_readfirstlane(v)) != 0; }
 #endif
 };
