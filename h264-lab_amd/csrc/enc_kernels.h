@@ -188,30 +188,32 @@ DEV void rv_wait_rect(const RefView &V, int x1, int y1)
 
 /* one lane per window row: four 16-byte loads when the window's columns lie inside the picture (uniform test),
  * clamped dword loads at the picture's left/right border */
-DEV void wave_load_window(uint8_t *win, const Plane &P, int wx0, int wy0)
+DEV void wave_load_window(uint8_t *win, const Plane &P, int wx0, int wy0, int narrow)
 {
-    const bool interior = wx0 >= 0 && wx0 + WIN_W <= P.w;
+    /* narrow geometry (h264e_dev.h): only 53 columns x 52 rows of the window are ever read: 52 rows of 56 bytes are loaded */
+    const int rows = narrow ? H264E_NARROW_VH : WIN_W, nq = narrow ? (H264E_NARROW_VW + 7)/8 : WIN_W/8;
+    const bool interior = wx0 >= 0 && wx0 + 8*nq <= P.w;
     WAVE_FOR(l)
     {
-        const int y = imin(imax(wy0 + l, 0), P.h - 1);
-        if (interior)
+        if (l < rows)
         {
-            const gu8 *src = P.p + (size_t)y*P.stride + wx0;        /* wx0 is a multiple of 8 */
-            uint64_t v[WIN_W/8];
-#pragma unroll
-            for (int g = 0; g < WIN_W/8; g++) v[g] = cload64(src + 8*g);
-#pragma unroll
-            for (int g = 0; g < WIN_W/8; g++)
+            const int y = imin(imax(wy0 + l, 0), P.h - 1);
+            if (interior)
             {
-                lds32_store(win + l*WIN_STRIDE + 8*g, (uint32_t)v[g]); lds32_store(win + l*WIN_STRIDE + 8*g + 4, (uint32_t)(v[g] >> 32));
+                const gu8 *src = P.p + (size_t)y*P.stride + wx0;        /* wx0 is a multiple of 8 */
+                uint64_t v[WIN_W/8];
+#pragma unroll
+                for (int g = 0; g < WIN_W/8; g++) if (g < nq) v[g] = cload64(src + 8*g);
+#pragma unroll
+                for (int g = 0; g < WIN_W/8; g++)
+                    if (g < nq)
+                    {
+                        lds32_store(win + l*WIN_STRIDE + 8*g, (uint32_t)v[g]); lds32_store(win + l*WIN_STRIDE + 8*g + 4, (uint32_t)(v[g] >> 32));
+                    }
+            } else
+            {
+                for (int g = 0; g < 2*nq; g++) lds32_store(win + l*WIN_STRIDE + 4*g, ref_load4(P, wx0 + 4*g, y));
             }
-        } else
-        {
-            uint32_t v[WIN_W/4];
-#pragma unroll
-            for (int g = 0; g < WIN_W/4; g++) v[g] = ref_load4(P, wx0 + 4*g, y);
-#pragma unroll
-            for (int g = 0; g < WIN_W/4; g++) lds32_store(win + l*WIN_STRIDE + 4*g, v[g]);
         }
     }
     wave_sync();

@@ -148,7 +148,7 @@ DEV void row_prefetch(RowLds &L, const h264e_geom_t &G, const h264e_frame_task_t
     {
         Plane P;
         P.p = (const gu8 *)T.ref[0]; P.w = G.W; P.h = G.H; P.stride = G.W;
-        wave_load_window(L.win, P, x*16 - WIN_M, row*16 - WIN_M);
+        wave_load_window(L.win, P, x*16 - WIN_M, row*16 - WIN_M, T.narrow);
     }
 }
 
