@@ -392,7 +392,7 @@ DEV int shr_opaque(int v, int s)
 #endif
     return t;
 }
-NOINLINE_DEV hp4_t halfpel3_win(const lu8 *at, int ox, int oy)
+DEV hp4_t halfpel3_win(const lu8 *at, int ox, int oy)
 {
     int th[6][4], cx[6][4];
 #pragma unroll
