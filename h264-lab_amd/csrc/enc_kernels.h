@@ -148,6 +148,7 @@ struct RefView
     int nmbx, nmby;
     int vw, vh;                 /* valid columns / rows of the window (h264e_dev.h: wide 64 x 64, narrow 53 x 52) */
     int *far;                   /* LDS counter of accesses that had to leave the window */
+    int *fail;                  /* LDS flag: a dynamic wait of this row gave up (spin bound expired): the row must stop and report */
 };
 
 /* wave-uniform: does the sample rectangle [x0,x1] x [y0,y1] lie inside the window? */
@@ -163,6 +164,10 @@ DEV const lu8 *rv_ptr(const RefView &V, int x, int y) { return V.win + (y - V.wy
  * the producing frame has finished -- reconstructed and deblocked -- the sample rectangle [x0,x1] x [y0,y1]:
  * a sample of macroblock (X,Y) is final once row Y+1 has passed column X (its top-edge filter), which in wavefront
  * order implies row Y passed X+2; on the last row, once row Y passed X+1.  Wave-uniform.
+ * Forward progress: this is the one wait that can target a workgroup LATER in the dispatch order (row Y+1 <= row+6 of the
+ * previous job, since vectors are clamped to 63 samples below the macroblock row, h264-lab.h:5181-5193): at most
+ * (12 - lag) dispatch keys = about (12 - lag)*(nmby+1)/2 workgroups ahead (8K: 1080), fewer than the ~2000 workgroups the
+ * dispatcher keeps resident beyond the oldest unfinished one -- and if that ever fails the bound below reports it.
  */
 DEV void rv_wait_rect(const RefView &V, int x1, int y1)
 {
@@ -176,8 +181,12 @@ DEV void rv_wait_rect(const RefView &V, int x1, int y1)
     for (;;)
     {
         const int seen = uni(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));      /* uni: scalar loop control */
-        if (seen >= need || seen < 0) break;        /* negative = the producer stopped (abort / failure): this row stops at its next macroblock */
-        if (++spins > (1u << 24)) break;            /* bounded: a stuck producer is reported by its own row loop */
+        if (seen >= need) break;
+        /* negative = the producer stopped (abort / failure); bound expired = the producer never got there.  Either way the
+         * samples behind this wait are not final: flag the row, which stops, poisons its counter and (for an expiry) raises the
+         * launch's error flag right after this macroblock (h264e_kernels.hip) -- nothing encoded from them is ever returned */
+        if (seen < 0) { if (V.fail) *V.fail = seen; break; }
+        if (++spins > (1u << 24)) { if (V.fail) *V.fail = -1; break; }
         __builtin_amdgcn_s_sleep(8);
     }
     consumer_acquire();

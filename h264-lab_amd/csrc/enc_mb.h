@@ -32,6 +32,7 @@ struct RowLds
     BitW bw;
     int skip_run, lead_skips, coded_any;
     int far_reads;                                  /* reference accesses of this row that left the valid window */
+    int far_fail;                                   /* a dynamic wait behind such an access gave up (enc_kernels.h rv_wait_rect): -1 expired, -2 producer aborted */
     unsigned long long prof[32], prof_last, prof_c0, prof_w0;
 
     /* ---- per macroblock */

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <time.h>
 #include <sched.h>
+#include <pthread.h>
 #include "../../include/h264e_mi355x.h"
 #include "../../include/h264e_hip.h"
 
@@ -25,7 +26,7 @@
 #define SLICE_I 2
 
 static int g_device = -1;
-static char g_host_err[256];
+static __thread char g_host_err[256];       /* per calling thread: encoders on different threads do not share error text */
 
 static int imin(int a, int b) { return a < b ? a : b; }
 static int imax(int a, int b) { return a > b ? a : b; }
@@ -182,7 +183,11 @@ static void seq_init(seq_t *s, int width, int height, int vbv, int sps_id)
 }
 
 /* h264-lab.h:4040-4141 encode_sps (profile 66) + h264-lab.h:4147-4176 encode_pps; returns bytes appended to d */
-static size_t write_sps_pps(const seq_t *s, int pic_init_qp, uint8_t *d)
+typedef void (*nalu_cb_t)(const unsigned char *nalu_data, int sizeof_nalu_data, void *token);
+
+/* cb (optional): the reference's nal_end() hands EVERY finished NAL -- parameter sets included -- to run_param.nalu_callback,
+ * pointer behind the start code, escaped length (h264-lab.h:4014-4018) */
+static size_t write_sps_pps(const seq_t *s, int pic_init_qp, uint8_t *d, nalu_cb_t cb, void *token)
 {
     static const struct { uint8_t level; uint16_t max_fs, max_vbvdiv5; uint32_t max_dpb; } lim[] = {
         { 10, 99, 175/5, 396 }, { 10, 99, 350/5, 396 }, { 11, 396, 500/5, 900 }, { 12, 396, 1000/5, 2376 },
@@ -214,6 +219,7 @@ static size_t write_sps_pps(const seq_t *s, int pic_init_qp, uint8_t *d)
     hb_put(&b, 1, 1);
     if (b.n) hb_put(&b, 8 - b.n, 0);
     n += nal_emit(d + n, tmp, b.pos);
+    if (cb) cb(d + 4, (int)(n - 4), token);
 
     memset(&b, 0, sizeof(b)); b.buf = tmp;
     hb_put(&b, 8, 0x68);
@@ -225,7 +231,11 @@ static size_t write_sps_pps(const seq_t *s, int pic_init_qp, uint8_t *d)
     hb_put(&b, 5, 0x1C);
     hb_put(&b, 1, 1);
     if (b.n) hb_put(&b, 8 - b.n, 0);
-    n += nal_emit(d + n, tmp, b.pos);
+    {
+        const size_t n0 = n;
+        n += nal_emit(d + n, tmp, b.pos);
+        if (cb) cb(d + n0 + 4, (int)(n - n0 - 4), token);
+    }
     return n;
 }
 
@@ -461,12 +471,17 @@ typedef struct
 } henc_t;
 
 /* The reference API has no destructor and callers simply free() the blob, so nothing that needs
- * releasing may be reachable only through it: pools and staging buffers sit in this registry, keyed by blob address. */
-typedef struct { void *owner; uint32_t serial; h264e_hip_pool_t *pool; uint8_t *rbsp; size_t rbsp_cap; uint8_t *recon; } impl_t;
-#define MAX_LIVE 64
-static impl_t g_impl[MAX_LIVE];
+ * releasing may be reachable only through it: pools and staging buffers sit in this registry, keyed by blob address.
+ * The registry grows on demand and is guarded by one mutex (H264E_init / H264E_close / H264E_encode's lookup may run on
+ * different threads for different encoders, like the reference's re-entrant instances).  An entry is reclaimed when
+ * H264E_close is called, when the same blob is initialised again, or when a NEW blob overlaps its address range (the
+ * caller freed the old blob and the allocator handed the memory out again: the old encoder cannot be alive). */
+typedef struct { void *owner; size_t owner_bytes; uint32_t serial; h264e_hip_pool_t *pool; uint8_t *rbsp; size_t rbsp_cap; uint8_t *recon; } impl_t;
+static impl_t *g_impl;
+static int g_impl_cap;
 static uint32_t g_serial;
 static int g_atexit;
+static pthread_mutex_t g_reg_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static void impl_release(impl_t *m)
 {
@@ -478,21 +493,42 @@ static void impl_release(impl_t *m)
 static void release_all(void)
 {
     int i;
-    for (i = 0; i < MAX_LIVE; i++) if (g_impl[i].owner) impl_release(g_impl + i);
+    pthread_mutex_lock(&g_reg_lock);
+    for (i = 0; i < g_impl_cap; i++) if (g_impl[i].owner) impl_release(g_impl + i);
+    pthread_mutex_unlock(&g_reg_lock);
 }
 
-static impl_t *impl_of(const henc_t *e)
+/* copy of the entry (the table may be reallocated by another thread's H264E_init): pointers inside stay valid as long as
+ * this encoder is not closed concurrently, which the API forbids per instance as the reference does */
+static int impl_of(const henc_t *e, impl_t *out)
 {
-    if (!e || e->magic != MAGIC || e->impl < 0 || e->impl >= MAX_LIVE) return NULL;
-    if (g_impl[e->impl].owner != (const void *)e || g_impl[e->impl].serial != e->serial) return NULL;
-    return g_impl + e->impl;
+    int ok = 0;
+    if (!e || e->magic != MAGIC) return 0;
+    pthread_mutex_lock(&g_reg_lock);
+    if (e->impl >= 0 && e->impl < g_impl_cap && g_impl[e->impl].owner == (const void *)e && g_impl[e->impl].serial == e->serial)
+    {
+        *out = g_impl[e->impl];
+        ok = 1;
+    }
+    pthread_mutex_unlock(&g_reg_lock);
+    return ok;
+}
+
+/* with the lock held: release every entry whose owner address lies in [p, p + n) */
+static void reclaim_range(const void *p, size_t n)
+{
+    int i;
+    for (i = 0; i < g_impl_cap; i++)
+        if (g_impl[i].owner && (const char *)g_impl[i].owner >= (const char *)p && (const char *)g_impl[i].owner < (const char *)p + (n ? n : 1))
+            impl_release(g_impl + i);
 }
 
 void H264E_close(H264E_persist_t *p)
 {
-    int i;
-    for (i = 0; i < MAX_LIVE; i++)
-        if (p && g_impl[i].owner == (void *)p) impl_release(g_impl + i);
+    if (!p) return;
+    pthread_mutex_lock(&g_reg_lock);
+    reclaim_range(p, 1);
+    pthread_mutex_unlock(&g_reg_lock);
 }
 
 /* h264-lab.h:6252-6286 enc_check_create_params (+ the options this implementation refuses) */
@@ -549,8 +585,8 @@ int H264E_sizeof(const H264E_create_param_t *par, int *sizeof_persist, int *size
 int H264E_init(H264E_persist_t *p, const H264E_create_param_t *par)
 {
     henc_t *e = (henc_t *)p;
-    impl_t *m;
-    int i, err = check_params(par);
+    impl_t fresh;
+    int i, sp, ss, err = check_params(par);
     g_host_err[0] = 0;
     if (!e) return H264E_STATUS_BAD_ARGUMENT;
     if (err) return err;
@@ -559,27 +595,41 @@ int H264E_init(H264E_persist_t *p, const H264E_create_param_t *par)
         snprintf(g_host_err, sizeof(g_host_err), "option outside the MI355X encode path (long-term refs, denoise, MB-level RC, VBV stuffing/empty frames, SVC)");
         return H264E_STATUS_BAD_PARAMETER;
     }
-    H264E_close(p);                             /* re-init of the same blob: drop the old device state */
-    for (i = 0; i < MAX_LIVE && g_impl[i].owner; i++) {}
-    if (i == MAX_LIVE)
-    {
-        snprintf(g_host_err, sizeof(g_host_err), "too many live encoders (%d): call H264E_close", MAX_LIVE);
-        return H264E_STATUS_BAD_ARGUMENT;
-    }
-    m = g_impl + i;
+    ref_sizes(par, &sp, &ss);
     memset(e, 0, sizeof(*e));
     e->param = *par;
     seq_init(&e->seq, par->width, par->height, par->vbv_size_bytes, par->sps_id);
-    if (h264e_hip_pool_create(&m->pool, pick_device(), par->width, par->height, 1, 1, 1))
+    /* device resources are created outside the lock (slow), registered under it */
+    memset(&fresh, 0, sizeof(fresh));
+    if (h264e_hip_pool_create(&fresh.pool, pick_device(), par->width, par->height, 1, 1, 1))
         return H264E_STATUS_BAD_ARGUMENT;       /* no device: the HIP path is the only path */
-    m->rbsp_cap = (size_t)e->seq.nmb*640 + 2048;
-    m->rbsp = (uint8_t *)malloc(m->rbsp_cap);
-    if (!par->const_input_flag) m->recon = (uint8_t *)malloc((size_t)e->seq.w*e->seq.h*3/2);
-    m->owner = e;
-    m->serial = e->serial = ++g_serial;
+    fresh.rbsp_cap = (size_t)e->seq.nmb*640 + 2048;
+    fresh.rbsp = (uint8_t *)malloc(fresh.rbsp_cap);
+    if (!par->const_input_flag) fresh.recon = (uint8_t *)malloc((size_t)e->seq.w*e->seq.h*3/2);
+    fresh.owner = e; fresh.owner_bytes = (size_t)sp;
+    pthread_mutex_lock(&g_reg_lock);
+    reclaim_range(p, (size_t)sp);               /* re-init of the same blob, or of memory an abandoned encoder lived in */
+    for (i = 0; i < g_impl_cap && g_impl[i].owner; i++) {}
+    if (i == g_impl_cap)
+    {
+        const int ncap = g_impl_cap ? 2*g_impl_cap : 16;
+        impl_t *t = (impl_t *)realloc(g_impl, sizeof(impl_t)*(size_t)ncap);
+        if (!t)
+        {
+            pthread_mutex_unlock(&g_reg_lock);
+            impl_release(&fresh);
+            snprintf(g_host_err, sizeof(g_host_err), "out of host memory");
+            return H264E_STATUS_BAD_ARGUMENT;
+        }
+        memset(t + g_impl_cap, 0, sizeof(impl_t)*(size_t)(ncap - g_impl_cap));
+        g_impl = t; g_impl_cap = ncap;
+    }
+    fresh.serial = e->serial = ++g_serial;
+    g_impl[i] = fresh;
     e->impl = i;
     e->magic = MAGIC;
     if (!g_atexit) { atexit(release_all); g_atexit = 1; }
+    pthread_mutex_unlock(&g_reg_lock);
     return H264E_STATUS_SUCCESS;
 }
 
@@ -600,7 +650,7 @@ int H264E_encode(H264E_persist_t *p, H264E_scratch_t *scratch, const H264E_run_p
                  unsigned char **coded_data, int *sizeof_coded_data)
 {
     henc_t *e = (henc_t *)p;
-    impl_t *m = impl_of(e);
+    impl_t mm, *m = impl_of(e, &mm) ? &mm : NULL;
     uint8_t *out = (uint8_t *)scratch;
     size_t out_pos = 0, cap;
     int frame_type, key, qp, sp, ss, n;
@@ -630,7 +680,7 @@ int H264E_encode(H264E_persist_t *p, H264E_scratch_t *scratch, const H264E_run_p
         e->pic_init_qp = imax(imin(30, e->run_param.qp_max), e->run_param.qp_min);       /* h264-lab.h:6768-6775 */
         e->next_idr_pic_id ^= 1;
         e->frame_num = 0;
-        out_pos += write_sps_pps(&e->seq, e->pic_init_qp, out + out_pos);
+        out_pos += write_sps_pps(&e->seq, e->pic_init_qp, out + out_pos, e->run_param.nalu_callback, e->run_param.nalu_callback_token);
     } else if (!e->pic_init_qp)
         return H264E_STATUS_BAD_FRAME_TYPE;                                              /* h264-lab.h:6801-6804 */
 
@@ -881,7 +931,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
                 const uint8_t *rb = h264e_hip_stream_rbsp(c->pool, slot);
                 size_t start = pos, need = nal_escaped_size(rb, r1.nbytes) + (key ? 64 : 0);
                 if (pos + need > cap) { snprintf(g_host_err, sizeof(g_host_err), "output buffer too small"); (void)h264e_hip_stream_abort(c->pool); (void)h264e_hip_sync(c->pool); goto done; }
-                if (key) pos += write_sps_pps(&c->seq, pic_init_qp, out + pos);
+                if (key) pos += write_sps_pps(&c->seq, pic_init_qp, out + pos, NULL, NULL);
                 pos += nal_emit(out + pos, rb, r1.nbytes);
                 if (frame_bytes) frame_bytes[f] = (int)(pos - start);
             }

@@ -2,12 +2,13 @@
  * h264e_kernels.hip -- HIP kernels of the per-frame encode path and their C-ABI launcher (include/h264e_hip.h).
  *
  * Kernels (gfx950, wave64):
- *   h264e_mb_kernel      one 64-lane workgroup per (chain, macroblock row); rows of one picture run as a
- *                        wavefront behind each other: row r may encode macroblock x once row r-1 has finished
- *                        macroblock x+1 (left, top-left, top, top-right neighbours + in-loop deblocking order).
- *                        The hand-off is a per-row progress counter with agent-scope release/acquire
- *                        (cdna_hip_programming.md Guideline 16).
- *   h264e_splice_kernel  one workgroup per chain: concatenates the row bit buffers into the slice RBSP.
+ *   h264e_mb_kernel      one 64-lane workgroup per (job, macroblock row) + one finalizer workgroup per job; rows of one
+ *                        picture run as a wavefront behind each other: row r may encode macroblock x once row r-1 has
+ *                        published x+2 macroblocks (left, top-left, top, top-right neighbours + in-loop deblocking order);
+ *                        consecutive frames of a stream run as a temporal wavefront a few steps apart.  Hand-off: per-row
+ *                        progress counters, payload stored write-through (sc1), relaxed polls, one acquire per hand-off
+ *                        (cdna_hip_programming.md Guideline 16 R1).  The finalizer splices the row bit buffers into the
+ *                        slice RBSP (there is no separate splice kernel) and exports the frame to host-mapped memory.
  *   h264e_synth_kernel   fills resident input frames with the synth_v1 clip (bench / test input in HBM).
  *
  * Built as the product with hipcc --offload-arch=gfx950.  The same file compiles with g++ -DH264E_EMU into
@@ -23,7 +24,7 @@
 #include <hip/hip_runtime.h>
 #endif
 
-static char g_err[256];
+static thread_local char g_err[256];       /* per calling thread */
 #define FAIL(...) do { snprintf(g_err, sizeof(g_err), __VA_ARGS__); return -1; } while (0)
 extern "C" const char *h264e_hip_last_error(void) { return g_err; }
 
@@ -53,8 +54,10 @@ DEV int poll_progress(const GLOBAL_AS int *flag, int need, int &seen)
  * `row` of its job's frame; workgroup `nmby` is the job's finalizer: once every row has ended it splices the slice
  * (finalize_frame) and, in streaming use, exports the result to host-mapped memory and raises the job's done word,
  * so the host consumes frames while later frames of the same launch are still being encoded.
- * Every workgroup only ever waits for workgroups with a lower index (rows above; rows of the reference frame's job;
- * rows of the own job for the finalizer).
+ * Every workgroup waits for workgroups with a lower index (rows above; rows of the reference frame's job inside the
+ * static lag; rows of the own job for the finalizer) -- with ONE exception: a reference read that leaves the LDS window
+ * (a long vector) waits dynamically for the exact rows it touches, which can lie a bounded distance AHEAD in the dispatch
+ * order (enc_kernels.h rv_wait_rect).  All spins are bounded; an expired one poisons the row counter and sets errflag.
  */
 template <bool NARROW>
 __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h264e_chain_dev_t *chains,
@@ -148,6 +151,19 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
         }
         STAMP(L, 13);
         row_step<NARROW>(L, G, C, T, row, x);
+        {
+            /* a far reference read of this macroblock waited in vain (rv_wait_rect): what it encoded is not trustworthy */
+            const int ff = uni(L.far_fail);
+            if (ff)
+            {
+                if (threadIdx.x == 0)
+                {
+                    if (ff == -1) *errflag = 1;
+                    __hip_atomic_store(C.progress + row, ff < -2 ? -2 : ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
+        }
         /* producer: every handed-off byte was stored write-through (sc1, wave.h cstore*): drain them, then the counter --
          * no agent-scope release (L2 write-back) needed */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/golden_big.json: md5 / sizes of FULL-LENGTH streams produced by the REFERENCE encoder
+(oracle/_ref/encode_app_ref, and oracle/_ref/encode_app_ref_thr for the multi-slice cases) on synth_v1 clips.
+
+Runs only in the build container (it executes the compiled reference).  Inputs are the synth_v1 clip (SURVEY.md
+Appendix A; oracle/build/synth_v1 writes it, tests/synth.py and the device generator reproduce it bit for bit);
+outputs are md5, total bytes and per-frame sizes -- data, not source.  Minutes of CPU: the 1080p x 600 bench stream
+alone is about 70 s of the reference.
+
+    python tests/golden/make_golden_big.py [case-name ...]
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref", "encode_app_ref")
+REF_THR = os.path.join(ROOT, "oracle", "_ref", "encode_app_ref_thr")
+SYNTH = os.path.join(ROOT, "oracle", "build", "synth_v1")
+OUT = os.path.join(HERE, "golden_big.json")
+
+CASES = {
+    # name: (w, h, frames, flags, binary)
+    "bench_1080p_600": (1920, 1080, 600, "--qp 26 --gop 30", REF),            # BASELINE configs[2]: the bench stream
+    "1080p_600_intra": (1920, 1080, 60, "--qp 26 --gop 1", REF),
+    "cif_300_gop30": (352, 288, 300, "--qp 26 --gop 30", REF),                 # configs[1] stand-in (foreman absent)
+    "cif_300_intra": (352, 288, 300, "--qp 26 --gop 1", REF),                  # configs[0] stand-in
+    "4k_30": (3840, 2160, 30, "--qp 26 --gop 30", REF),                        # configs[3] geometry
+    "8k_4": (7680, 4320, 4, "--qp 26 --gop 30", REF),                          # configs[4] geometry, single slice
+    "1080p_30_kbps": (1920, 1080, 30, "--kbps 4000 --gop 30", REF),            # frame-level rate control
+    "cif_60_kbps": (352, 288, 60, "--kbps 500 --gop 30", REF),
+    # multi-slice (row bands), reference built with -DH264E_MAX_THREADS=8
+    "cif_30_thr2": (352, 288, 30, "--qp 26 --gop 30 --threads 2", REF_THR),
+    "cif_30_thr4": (352, 288, 30, "--qp 26 --gop 30 --threads 4", REF_THR),
+    "1080p_30_thr8": (1920, 1080, 30, "--qp 26 --gop 30 --threads 8", REF_THR),
+    "8k_3_thr2": (7680, 4320, 3, "--qp 26 --gop 30 --threads 2", REF_THR),     # F6: the reference aborts at >= 3 slices at 8K
+    "8k_3_thr2_kbps": (7680, 4320, 3, "--kbps 60000 --gop 30 --threads 2", REF_THR),   # configs[4]: multi-slice + rate control
+    "1080p_20_thr8_kbps": (1920, 1080, 20, "--kbps 4000 --gop 30 --threads 8", REF_THR),
+}
+
+
+def run_case(name, tmp):
+    w, h, n, flags, binary = CASES[name]
+    yuv = os.path.join(tmp, "sv1_%d_%dx%d.yuv" % (n, w, h))
+    if not os.path.exists(yuv):
+        subprocess.check_call([SYNTH, str(w), str(h), str(n), yuv])
+    o = os.path.join(tmp, "o.264")
+    t0 = time.time()
+    r = subprocess.run([binary, "--input", yuv, "--output", o] + flags.split() + ["--stats", "x"], capture_output=True, text=True, check=True)
+    dt = time.time() - t0
+    data = open(o, "rb").read()
+    sizes = [int(l.split("bytes=")[1]) for l in r.stdout.splitlines() if l.startswith("frame=")]
+    assert len(sizes) == n and sum(sizes) == len(data)
+    h5 = hashlib.md5()
+    with open(yuv, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h5.update(blk)
+    os.remove(yuv)
+    e = dict(clip="synth", w=w, h=h, frames=n, flags=flags, input_md5=h5.hexdigest(), bytes=len(data),
+             md5=hashlib.md5(data).hexdigest(), frame_bytes=sizes, ref_seconds=round(dt, 1),
+             binary=os.path.basename(binary))
+    print(name, e["bytes"], e["md5"], "%.1f s" % dt, flush=True)
+    return e
+
+
+def main():
+    names = sys.argv[1:] or list(CASES)
+    have = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for name in names:
+            have[name] = run_case(name, tmp)
+            json.dump(have, open(OUT, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
