@@ -3,7 +3,7 @@
  *
  * A scalar C restatement of the reference encoder's per-frame path
  * (/root/reference/src/h264-lab.h:6654-6861 H264E_encode and everything below
- * it), constant-QP mode, single slice, one reference frame.  Used only by
+ * it), constant-QP or frame-level rate control, one slice or N row-band slices per frame, one reference frame.  Used only by
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the
  * checker for the HIP path; never linked into the product library.
  */
@@ -23,6 +23,8 @@ typedef struct
     int speed;              /* encode_speed: 0 best ... 10 fastest (H:76-78) */
     int vbv_size_bytes;     /* only selects the SPS level here; encode_app passes 12500 (T:524) */
     int kbps;               /* 0 = constant QP; else frame-level rate control like encode_app --kbps (T:596-600) */
+    int slices;             /* 0 / 1 = one slice per frame; N > 1 = N row bands, the reference's -DH264E_MAX_THREADS build with
+                               --threads N (H:6511-6574): per-band slices with deblock idc 2, mv_clusters restarted per band */
 } h264o_param_t;
 
 /* per-macroblock decision record, for debugging a second implementation against the oracle */

@@ -27,6 +27,7 @@ struct h264o_enc
     rect_t mv_limit, mv_qlimit;                         /* H:6322-6325 */
 
     int frame_num, next_idr_pic_id, pic_init_qp, frames_done;
+    int slice_start_num, slice_start_row;               /* H:4185 slice.start_mb_num (row bands, H:6526-6534) */
     mv32 clusters[2];                                   /* H:766 */
 
     int slice_type, qp, prev_qp, speed, no_deblock;
@@ -89,10 +90,11 @@ static inline int mv_cost(const h264o_enc_t *e, mv32 v, mv32 pred)       /* H:49
 /* H:3605-3622 */
 static int avail_flags(const h264o_enc_t *e, const mb_t *m)
 {
-    int f = m->num >= e->nmbx;                          /* single slice: start_mb_num = 0 */
-    if (m->num >= e->nmbx - 1 && m->x != e->nmbx - 1) f += AV_TR;
-    if (m->num != 0 && m->x) f += AV_L;
-    if (m->num > e->nmbx && m->x) f += AV_TL;
+    const int s0 = e->slice_start_num;
+    int f = m->num >= s0 + e->nmbx;
+    if (m->num >= s0 + e->nmbx - 1 && m->x != e->nmbx - 1) f += AV_TR;
+    if (m->num != s0 && m->x) f += AV_L;
+    if (m->num > s0 + e->nmbx && m->x) f += AV_TL;
     return f;
 }
 
@@ -823,7 +825,7 @@ static void mb_deblock(h264o_enc_t *e, const mb_t *m)
     if (m->type >= 5 || e->df_type[m->x] >= 5) memset(bs + 16, 4, 4);
     e->df_type[m->x] = (int8_t)m->type;
     if (!m->x) memset(bs, 0, 4);
-    if (!m->y) memset(bs + 16, 0, 4);
+    if (m->y == e->slice_start_row) memset(bs + 16, 0, 4);          /* picture top, or H:5799-5803: no filtering across a slice border */
     qp_top = e->df_qp[m->x];
     qp_left = m->x ? e->df_qp[m->x - 1] : qp;
     e->df_qp[m->x] = (uint8_t)qp;
@@ -954,7 +956,7 @@ static void write_slice_header(h264o_enc_t *e, int key)
 {
     bitw_t *b = &e->bw;
     nal_begin(e, key ? 0x65 : 0x61);
-    bw_ue(b, 0);                                    /* first_mb_in_slice */
+    bw_ue(b, (uint32_t)e->slice_start_num);         /* first_mb_in_slice */
     bw_ue(b, (uint32_t)e->slice_type);
     bw_ue(b, 0);                                    /* pps id */
     bw_put(b, 5, (uint32_t)(e->frame_num & 31));
@@ -963,7 +965,7 @@ static void write_slice_header(h264o_enc_t *e, int key)
     if (key) bw_put(b, 2, 0);                       /* no_output_of_prior_pics_flag, long_term_reference_flag */
     else bw_put(b, 1, 0);                           /* adaptive_ref_pic_marking_mode_flag */
     bw_se(b, e->prev_qp - e->pic_init_qp);
-    bw_ue(b, (uint32_t)e->no_deblock);
+    bw_ue(b, (uint32_t)(e->par.slices > 1 ? (e->no_deblock ? 1 : 2) : e->no_deblock));      /* H:4315-4323: idc 2 with row-band slices */
     if (e->no_deblock != 1) bw_put(b, 2, 3);
 }
 
@@ -1181,20 +1183,36 @@ int h264o_encode(h264o_enc_t *e, const uint8_t *const yuv[3], const int stride[3
     e->slice_type = key ? SLICE_I : SLICE_P;
     rc_frame_start(e, key);
 
-    write_slice_header(e, key);
-    e->skip_run = 0;
-    memset(e->i4_top, -1, (size_t)e->nmbx*4); memset(e->i4_left, -1, 4);
-    memset(e->nnz_top, NNZ_NA, (size_t)e->nmbx*8); memset(e->nnz_left, NNZ_NA, 8);
-    for (y = 0; y < e->nmby; y++)
     {
-        for (x = 0; x < e->nmbx; x++) encode_mb(e, x, y);
-        memset(e->nnz_left, NNZ_NA, 8);
-        memset(e->i4_left, -1, 4);
+        /* one slice, or N row bands (H:6511-6574): every band is a slice of its own -- contexts, availability, skip run and
+         * the mv_clusters state restart at its first macroblock (the reference encodes each band with a COPY of the encoder and
+         * throws the copy away, so the parent's mv_clusters never move, H:6526) */
+        const int nsl = e->par.slices > 1 ? e->par.slices : 1;
+        const mv32 c0 = e->clusters[0], c1 = e->clusters[1];
+        int band, row0 = 0;
+        for (band = 0; band < nsl; band++)
+        {
+            const int row1 = row0 + (e->nmby - row0)/(nsl - band);
+            e->slice_start_row = row0; e->slice_start_num = row0*e->nmbx;
+            write_slice_header(e, key);
+            e->skip_run = 0;
+            memset(e->i4_top, -1, (size_t)e->nmbx*4); memset(e->i4_left, -1, 4);
+            memset(e->nnz_top, NNZ_NA, (size_t)e->nmbx*8); memset(e->nnz_left, NNZ_NA, 8);
+            for (y = row0; y < row1; y++)
+            {
+                for (x = 0; x < e->nmbx; x++) encode_mb(e, x, y);
+                memset(e->nnz_left, NNZ_NA, 8);
+                memset(e->i4_left, -1, 4);
+            }
+            if (e->skip_run) bw_ue(&e->bw, (uint32_t)e->skip_run);
+            nal_finish(e);
+            if (nsl > 1) { e->clusters[0] = c0; e->clusters[1] = c1; e->skip_run = 0; }
+            row0 = row1;
+        }
+        e->slice_start_row = e->slice_start_num = 0;
     }
-    if (e->skip_run) bw_ue(&e->bw, (uint32_t)e->skip_run);
-    nal_finish(e);
 
-    rc_frame_end(e, key, e->skip_run == e->nmb);
+    rc_frame_end(e, key, e->par.slices > 1 ? 0 : e->skip_run == e->nmb);       /* the parent's skip_run stays 0 in the threads build (H:6596) */
     for (c = 0; c < 3; c++)
     {
         uint8_t *t = e->ref[c]; e->ref[c] = e->dec[c]; e->dec[c] = t;      /* H:3580-3596 */

@@ -1,7 +1,7 @@
 /*
  * oracle_app -- command-line front end of the CPU oracle (TEST INFRASTRUCTURE).
  * Accepts the subset of the reference encode_app options the oracle models
- * (/root/reference/src/minih264e_test.c:133-224): --input --output --qp --gop --speed --kbps.
+ * (/root/reference/src/minih264e_test.c:133-224): --input --output --qp --gop --speed --kbps --threads (row-band slices of the -DH264E_MAX_THREADS build).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -26,6 +26,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--gop")) par.gop = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--speed")) par.speed = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--kbps")) par.kbps = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--threads")) par.slices = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--size")) sscanf(argv[i + 1], "%dx%d", &w, &h);
         else if (!strcmp(argv[i], "--frames")) n = atoi(argv[i + 1]);
     }

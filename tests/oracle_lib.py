@@ -7,10 +7,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "oracle", "build", "liboracle_h264.so")
 REF_APP = os.path.join(ROOT, "oracle", "_ref", "encode_app_ref")
+REF_APP_THR = os.path.join(ROOT, "oracle", "_ref", "encode_app_ref_thr")       # -DH264E_MAX_THREADS=8 build: --threads N = N slices
 
 
 class Param(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("width", "height", "gop", "qp", "speed", "vbv_size_bytes", "kbps")]
+    _fields_ = [(n, C.c_int) for n in ("width", "height", "gop", "qp", "speed", "vbv_size_bytes", "kbps", "slices")]
 
 
 class Chain(C.Structure):
@@ -43,18 +44,18 @@ def lib():
     return _lib
 
 
-def make_param(w, h, gop=30, qp=26, speed=0, kbps=0):
-    return Param(w, h, gop, qp, speed, 100000 // 8, kbps)
+def make_param(w, h, gop=30, qp=26, speed=0, kbps=0, slices=0):
+    return Param(w, h, gop, qp, speed, 100000 // 8, kbps, slices)
 
 
-def encode_clip(clip, w, h, gop=30, qp=26, speed=0, kbps=0):
+def encode_clip(clip, w, h, gop=30, qp=26, speed=0, kbps=0, slices=0):
     """clip: uint8 array [nframes, w*h*3/2].  Returns (bitstream bytes, per-frame sizes)."""
     clip = np.ascontiguousarray(clip, dtype=np.uint8)
     n = clip.shape[0]
     cap = clip.size * 2 + (1 << 16)
     out = np.empty(cap, np.uint8)
     sizes = (C.c_int * n)()
-    par = make_param(w, h, gop, qp, speed, kbps)
+    par = make_param(w, h, gop, qp, speed, kbps, slices)
     r = lib().h264o_encode_clip(C.byref(par), clip.ctypes.data, n, out.ctypes.data, cap, sizes)
     assert r >= 0
     return out[:r].tobytes(), list(sizes)
@@ -63,9 +64,9 @@ def encode_clip(clip, w, h, gop=30, qp=26, speed=0, kbps=0):
 class Encoder:
     """Frame-at-a-time oracle encoder with access to recon, trace and the GOP hand-off state."""
 
-    def __init__(self, w, h, gop=30, qp=26, speed=0, kbps=0):
+    def __init__(self, w, h, gop=30, qp=26, speed=0, kbps=0, slices=0):
         self.w, self.h = w, h
-        self.par = make_param(w, h, gop, qp, speed, kbps)
+        self.par = make_param(w, h, gop, qp, speed, kbps, slices)
         self.e = lib().h264o_open(C.byref(self.par))
         assert self.e
 
