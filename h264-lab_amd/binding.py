@@ -41,7 +41,7 @@ class IoYuv(C.Structure):  # h264-lab.h:231-237: 40 bytes
 
 class ClipParam(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("width", "height", "gop", "qp", "speed", "vbv_size_bytes", "device", "max_chains",
-                                       "first_idr_pic_id_state")] + [("mv_clusters_in", C.c_int32 * 2)]
+                                       "first_idr_pic_id_state")] + [("mv_clusters_in", C.c_int32 * 2), ("slices", C.c_int), ("kbps", C.c_int)]
 
 
 class ClipStats(C.Structure):
@@ -74,6 +74,7 @@ def load(path=None):
     L.H264E_encode.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(RunParam), C.POINTER(IoYuv), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     L.H264E_set_vbv_state.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.H264E_set_vbv_state.restype = None
+    L.H264E_set_slices.argtypes = [C.c_void_p, C.c_int]
     L.H264E_close.argtypes = [C.c_void_p]
     L.H264E_close.restype = None
     L.H264E_set_device.argtypes = [C.c_int]
@@ -97,7 +98,7 @@ def _err(L, what):
 class Encoder:
     """Frame-at-a-time encoder through the reference API: H264E_sizeof -> H264E_init -> H264E_encode."""
 
-    def __init__(self, width, height, gop=20, qp=33, speed=0, kbps=0, const_input=1, vbv_size_bytes=100000 // 8, lib=None):
+    def __init__(self, width, height, gop=20, qp=33, speed=0, kbps=0, const_input=1, vbv_size_bytes=100000 // 8, lib=None, slices=0):
         self.L = load(lib)
         self.w, self.h = width, height
         self.cp = CreateParam(width=width, height=height, gop=gop, vbv_size_bytes=vbv_size_bytes, const_input_flag=const_input,
@@ -112,6 +113,8 @@ class Encoder:
         st = self.L.H264E_init(self.persist, C.byref(self.cp))
         if st:
             raise _err(self.L, "H264E_init status %d" % st)
+        if slices and self.L.H264E_set_slices(self.persist, slices):
+            raise H264EError("H264E_set_slices(%d) refused" % slices)
         self.rp = RunParam(encode_speed=speed)
         if kbps:
             self.rp.desired_frame_bytes = kbps * 1000 // 8 // 30  # minih264e_test.c:596-600
@@ -148,10 +151,10 @@ class ClipEncoder:
     """Whole-clip streaming encode on one GPU (H264E_clip_* extension): consecutive frames as a temporal wavefront."""
 
     def __init__(self, width, height, nframes, gop=30, qp=26, speed=0, device=0, max_chains=0, lib=None,
-                 clusters_in=(0, 0), idr_state=0):
+                 clusters_in=(0, 0), idr_state=0, slices=0, kbps=0):
         self.L = load(lib)
         self.w, self.h, self.n = width, height, nframes
-        self.par = ClipParam(width, height, gop, qp, speed, 100000 // 8, device, max_chains, idr_state, (C.c_int32 * 2)(*clusters_in))
+        self.par = ClipParam(width, height, gop, qp, speed, 100000 // 8, device, max_chains, idr_state, (C.c_int32 * 2)(*clusters_in), slices, kbps)
         self.c = C.c_void_p()
         if self.L.H264E_clip_open(C.byref(self.c), C.byref(self.par), nframes):
             raise _err(self.L, "H264E_clip_open")

@@ -81,6 +81,7 @@ struct MbCtx
     RefView rv;                                     /* reference luma through the LDS window */
     gu8 *dec[3];
     int x, y, num, avail, type, cost, i16_mode, cropped, used_cand;
+    int slice_top;                                  /* first macroblock row of its slice: nothing above is used or filtered */
     mv32 mv_skip_pred;
     unsigned nz_mask;
     int qp;
@@ -914,7 +915,7 @@ DEV void df_strength(RowLds &L, const MbCtx &m, int top_type)
             if (i < 4)
             {
                 if (dir ? strong_t : strong_l) s = 4;
-                if (dir ? !m.y : !m.x) s = 0;
+                if (dir ? m.slice_top : !m.x) s = 0;          /* picture edge; h264-lab.h:5799-5803 no filtering across a slice's top edge */
             }
             L.bs[l] = (uint8_t)s;
         }

@@ -153,8 +153,12 @@ DEV void row_prefetch(RowLds &L, const h264e_geom_t &G, const h264e_frame_task_t
 }
 
 /* NARROW: compile-time choice of the reference-window geometry (h264e_dev.h) */
-template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, int row, int x)
+/* row0 / row1: first row and end row of the slice (row band) this row belongs to -- the whole picture for one slice per frame.
+ * A slice is encoded like a picture of its own as far as neighbour availability, contexts and deblocking are concerned
+ * (h264-lab.h:3605-3622 mb_avail_flag relative to slice.start_mb_num, h264-lab.h:5799-5808 no filtering across its top edge). */
+template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, int row, int x, int row0, int row1)
 {
+    const bool have_top = row > row0;
     MbCtx m;
     PTIC();
     m.G = &G; m.T = &T;
@@ -165,7 +169,8 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
         m.dec[c] = (gu8 *)T.dec[c];
     }
     m.x = x; m.y = row; m.num = row*G.nmbx + x;
-    m.avail = (row > 0 ? AV_T : 0) | (row > 0 && x != G.nmbx - 1 ? AV_TR : 0) | (x > 0 ? AV_L : 0) | (row > 0 && x > 0 ? AV_TL : 0);
+    m.avail = (have_top ? AV_T : 0) | (have_top && x != G.nmbx - 1 ? AV_TR : 0) | (x > 0 ? AV_L : 0) | (have_top && x > 0 ? AV_TL : 0);
+    m.slice_top = !have_top;
     m.cropped = G.cropping && ((x + 1)*16 > G.width || (row + 1)*16 > G.height);
     m.type = 0; m.cost = 0x7FFFFFFF; m.i16_mode = 0; m.used_cand = 0; m.mv_skip_pred = 0; m.nz_mask = 0;
     m.qp = T.qp;
@@ -174,7 +179,7 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
 
     GLOBAL_AS h264e_mbbottom_t *rowrec = C.bottom + (size_t)row*G.nmbx;
     STAMP(L, 0);
-    load_top(L, G, rowrec - G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, row > 0);
+    load_top(L, G, rowrec - G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, have_top);
     /* the input macroblock and the reference window are already in LDS (row_prefetch) */
     m.rv.dep = (const GLOBAL_AS int *)T.dep_progress; m.rv.nmbx = G.nmbx; m.rv.nmby = G.nmby;
     m.rv.P = m.ref[0]; m.rv.win = (const lu8 *)L.win; m.rv.has_win = T.slice_type == 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
@@ -238,7 +243,7 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
     gu8 *dy = m.dec[0] + (size_t)(row*16)*W + x*16;
     gu8 *du = m.dec[1] + (size_t)(row*8)*Wc + x*8, *dv = m.dec[2] + (size_t)(row*8)*Wc + x*8;
     GLOBAL_AS h264e_mbpend_t *pend_row = C.pend + (size_t)row*G.nmbx;
-    const bool direct = T.no_deblock || row == G.nmby - 1;      /* nothing below will filter the bottom lines: they are final now */
+    const bool direct = T.no_deblock || row == row1 - 1;        /* nothing below will filter the bottom lines (picture or slice end): they are final now */
     if (!T.no_deblock)
     {
         df_strength(L, m, L.top_type);
@@ -254,13 +259,13 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
             {
                 int r = (l - 32) >> 2, c = l & 3;
                 uint32_t v = 0;
-                if (row > 0) v = lds32(L.ptop + 16*r + 4*c);
+                if (have_top) v = lds32(L.ptop + 16*r + 4*c);
                 lds32_store(L.ytile + r*YT_STRIDE + 4 + 4*c, v);
             } else if (l < 56)
             {
                 int pl = (l >> 2) & 1, r = (l >> 1) & 1, c = l & 1;
                 uint32_t v = 0;
-                if (row > 0) v = lds32(L.ptop + 64 + 16*pl + 8*r + 4*c);
+                if (have_top) v = lds32(L.ptop + 64 + 16*pl + 8*r + 4*c);
                 memcpy(L.ctile[pl] + r*CT_STRIDE + 2 + 4*c, &v, 4);
             }
         }
@@ -303,7 +308,7 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
             } else if (l < 24)
             {
                 int r = (l - 16) >> 1, hf = l & 1;                          /* tile rows 0..3 = picture rows -4..-1 */
-                if (row > 0)
+                if (have_top)
                 {
                     const uint8_t *t = L.ytile + r*YT_STRIDE + 4 + 8*hf;
                     cstore64(dy - (size_t)(4 - r)*W + 8*hf, (uint64_t)lds32(t) | ((uint64_t)lds32(t + 4) << 32));
@@ -324,7 +329,7 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
             } else if (l < 52)
             {
                 int pl = (l - 48) >> 1, r = l & 1;                          /* tile rows 0..1 = picture rows -2..-1 */
-                if (row > 0)
+                if (have_top)
                 {
                     uint32_t lo, hi;
                     memcpy(&lo, L.ctile[pl] + r*CT_STRIDE + 2, 4); memcpy(&hi, L.ctile[pl] + r*CT_STRIDE + 6, 4);
@@ -462,31 +467,49 @@ DEV void clusters_step(mv32 c[2], mv32 mv)                                  /* h
 DEV void finalize_frame(const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, GLOBAL_AS int *stepflags)
 {
     SpliceState s;
-    const uint32_t start = T.arena_reset ? 0u : ((*C.cursor + 3u) & ~3u);
-    s.out = (GLOBAL_AS uint32_t *)(C.arena + start);
-    s.wpos = 0; s.carry = 0; s.cbits = 0; s.overflow = 0;
-    s.cap_words = (C.arena_cap - start) >> 2;
-    splice_put(s, T.hdr_nbits, T.hdr_bits);
-    int run = 0, overflow = 0;
-    for (int row = 0; row < G.nmby; row++)
+    const uint32_t start = T.arena_reset ? 0u : ((*C.cursor + 15u) & ~15u);
+    uint32_t off = 0;                                                           /* of the current slice, relative to start */
+    int overflow = 0, all_skipped = 0, spl_overflow = 0;
+    GLOBAL_AS h264e_frameout_t &F = C.fout[T.frame_slot];
+    /* one RBSP per slice (row band); the slices of a frame lie behind each other, each starting 16-byte aligned */
+    for (int k = 0; k < T.nslices; k++)
     {
-        const GLOBAL_AS h264e_rowmeta_t &M = C.rowmeta[row];
-        overflow |= M.overflow;
-        run += M.lead_skips;
-        if (M.lead_skips < G.nmbx || M.nbits)
+        const int r0 = T.slice_row[k], r1 = T.slice_row[k + 1];
+        const uint32_t room = start + off < C.arena_cap ? C.arena_cap - (start + off) : 0u;
+        s.out = (GLOBAL_AS uint32_t *)(C.arena + start + off);
+        s.wpos = 0; s.carry = 0; s.cbits = 0; s.overflow = 0;
+        s.cap_words = room >> 2;
+        splice_put(s, 8, (uint64_t)(uint32_t)T.hdr_nal);
+        put_ue64(s, (uint32_t)(r0*G.nmbx));                                     /* first_mb_in_slice, h264-lab.h:4247 */
+        splice_put(s, T.hdr_nbits, T.hdr_bits);
+        int run = 0;
+        for (int row = r0; row < r1; row++)
         {
-            if (T.slice_type != 2) put_ue64(s, (uint32_t)run);
-            wave_sync();
-            splice_words(s, C.rowbits + (size_t)row*G.row_words, M.nbits);
-            wave_sync();
-            run = M.trail_skips;
+            const GLOBAL_AS h264e_rowmeta_t &M = C.rowmeta[row];
+            overflow |= M.overflow;
+            run += M.lead_skips;
+            if (M.lead_skips < G.nmbx || M.nbits)
+            {
+                if (T.slice_type != 2) put_ue64(s, (uint32_t)run);
+                wave_sync();
+                splice_words(s, C.rowbits + (size_t)row*G.row_words, M.nbits);
+                wave_sync();
+                run = M.trail_skips;
+            }
         }
+        /* rc_frame_end's skip flag (h264-lab.h:6596): in the row-band build the parent's skip_run is never touched, so it is 0 there */
+        if (T.nslices == 1) all_skipped = run == G.nmb;
+        if (run) put_ue64(s, (uint32_t)run);                                    /* h264-lab.h:6451-6454 */
+        splice_put(s, 1, 1);                                                    /* rbsp_stop_one_bit, h264-lab.h:3999 */
+        const uint32_t nbytes = s.wpos*4 + (uint32_t)((s.cbits + 7) >> 3);
+        if (s.cbits) { int pad = 32 - s.cbits; splice_put(s, pad, 0); }
+        spl_overflow |= s.overflow;
+        F.slice_nbytes[k] = nbytes;
+        if (k + 1 < T.nslices) off += (nbytes + 15u) & ~15u; else off += nbytes;
+        wave_sync();
     }
-    const int all_skipped = run == G.nmb;
-    if (run) put_ue64(s, (uint32_t)run);                                    /* h264-lab.h:6451-6454 */
-    splice_put(s, 1, 1);                                                    /* rbsp_stop_one_bit, h264-lab.h:3999 */
-    uint32_t nbytes = s.wpos*4 + (uint32_t)((s.cbits + 7) >> 3);
-    if (s.cbits) { int pad = 32 - s.cbits; splice_put(s, pad, 0); }
+    const uint32_t nbytes = off;
+    s.overflow = spl_overflow;
 
     /* mv_clusters speculation check: is the speculated state a fixed point of every update of this frame? */
     const GLOBAL_AS h264e_mbrec_t *rec = C.mbrec + (size_t)T.frame_slot*G.nmb;
@@ -505,9 +528,9 @@ DEV void finalize_frame(const h264e_geom_t &G, const ChainG &C, const h264e_fram
             if (bad) moved = 1;
         }
     }
-    GLOBAL_AS h264e_frameout_t &F = C.fout[T.frame_slot];
     F.offset = start;
     F.nbytes = nbytes;
+    F.nslices = T.nslices;
     F.all_skipped = all_skipped;
     F.clusters_moved = moved;
     F.overflow = overflow | s.overflow;
@@ -517,7 +540,7 @@ DEV void finalize_frame(const h264e_geom_t &G, const ChainG &C, const h264e_fram
     F.far_reads = __hip_atomic_load(C.far_reads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wave_lane() == 0) __hip_atomic_store(C.far_reads, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-    *C.cursor = start + ((nbytes + 3u) & ~3u);
+    *C.cursor = start + ((nbytes + 15u) & ~15u);
     stepflags[0] = moved;
     stepflags[1] = overflow | s.overflow;
     wave_sync();

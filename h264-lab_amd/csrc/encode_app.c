@@ -10,7 +10,9 @@
  * when 0 (T:576); --kbps K -> desired_frame_bytes = K*1000/8/30, qp 10..50 (T:596-600); vbv_size_bytes = 12500
  * (T:524); --psnr makes const_input_flag 0 and prints the reference's PSNR line (T:331-405, T:521);
  * stdout carries "sizeof_persist = %d sizeof_scratch = %d" and, with --stats, "frame=%d, bytes=%d" (T:568, T:650).
- * Not kept: --gen (libm-dependent synthetic input), --threads (multi-slice build option), --denoise.
+ * --threads N (T:34-111, T:163) = N row-band slices per frame, the bitstream of the reference built with -DH264E_MAX_THREADS
+ * (no host threads are involved here: the slices are wavefronts of the same kernel launch).
+ * Not kept: --gen (libm-dependent synthetic input), --denoise.
  *
  * Extras (new option names, also argv-consuming): --device N; --clip 1 encodes the whole file through the
  * GOP-parallel clip encoder (H264E_clip_*; same bitstream, constant QP only); --chains N bounds chains in flight.
@@ -25,7 +27,7 @@ static struct
 {
     char input_file[1024], output_file[1024], recon_file[1024];
     int have_input, have_output;
-    int gop, qp, kbps, max_frames, speed, stats, psnr, device, clip, chains;
+    int gop, qp, kbps, max_frames, speed, stats, psnr, device, clip, chains, threads;
 } cmd;
 
 static int starts(const char *pattern, const char *p) { return !strncmp(pattern, p, strlen(pattern)); }
@@ -38,6 +40,7 @@ static void parse_long(const char *p, const char *val)
     else if (starts("kbps", p)) cmd.kbps = atoi(v);
     else if (starts("maxframes", p)) cmd.max_frames = atoi(v);
     else if (starts("speed", p)) cmd.speed = atoi(v);
+    else if (starts("threads", p)) cmd.threads = atoi(v);       /* T:163-166: N row-band slices per frame (the reference's H264E_MAX_THREADS build) */
     else if (starts("stats", p)) cmd.stats = 1;
     else if (starts("psnr", p)) cmd.psnr = 1;
     else if (starts("output", p)) { snprintf(cmd.output_file, sizeof(cmd.output_file), "%s", v); cmd.have_output = 1; }
@@ -80,7 +83,7 @@ static int read_cmdline(int argc, char **argv)
                "    4sif cif sif pal ntsc d1 16cif 16sif 720p 4SVGA 4XGA 16VGA 16VGA\n"
                "Options (every --option takes a value):\n"
                "    --input,  -i <f>  --output, -o <f>  --gop <n>  --qp <n>  --kbps <n>  --maxframes <n>\n"
-               "    --speed <n>  --stats x  --psnr x  --device <n>  --clip 1  --chains <n>\n");
+               "    --speed <n>  --threads <n>  --stats x  --psnr x  --device <n>  --clip 1  --chains <n>\n");
         return 0;
     }
     return 1;
@@ -165,7 +168,7 @@ static int run_clip_mode(FILE *fin, FILE *fout, int w, int h)
     if (n <= 0) return 0;
     memset(&par, 0, sizeof(par));
     par.width = w; par.height = h; par.gop = cmd.gop; par.qp = cmd.qp; par.speed = cmd.speed; par.vbv_size_bytes = 100000/8;
-    par.device = cmd.device < 0 ? 0 : cmd.device; par.max_chains = cmd.chains;
+    par.device = cmd.device < 0 ? 0 : cmd.device; par.max_chains = cmd.chains; par.slices = cmd.threads;
     buf = (uint8_t *)malloc(fsz*(size_t)n);
     out = (uint8_t *)malloc(fsz*(size_t)n + (1 << 20));
     sizes = (int *)malloc(sizeof(int)*(size_t)n);
@@ -232,6 +235,7 @@ int main(int argc, char **argv)
     if (!buf_in || !buf_save || !enc || !scratch) { printf("ERROR: not enough memory\n"); return 1; }
     error = H264E_init(enc, &create_param);
     if (error) { printf("H264E_init error = %d (%s)\n", error, H264E_last_error()); return 1; }
+    if (cmd.threads > 1 && H264E_set_slices(enc, cmd.threads)) { printf("ERROR: --threads %d not supported\n", cmd.threads); return 1; }
 
     for (i = 0; cmd.max_frames; i++)
     {

@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #define H264E_MV_NA 0x8000
+#define H264E_MAX_SLICES 16             /* row-band slices per frame (== H264E_HIP_MAX_SLICES) */
 #define H264E_ROW_BYTES_PER_MB 2048     /* capacity of a row bit buffer, per macroblock of the row */
 
 /* Temporal wavefront (a P frame starts while its reference frame is still being encoded): macroblock (x, row) needs the
@@ -89,8 +90,11 @@ typedef struct
 
 typedef struct
 {
-    uint32_t offset;                    /* byte offset of the RBSP in the chain's arena */
-    uint32_t nbytes;
+    uint32_t offset;                    /* byte offset of the frame's first slice RBSP in the chain's arena; slice k follows at the
+                                           sum of the 16-byte-rounded sizes of the slices before it */
+    uint32_t nbytes;                    /* span of all slices (last one not rounded) */
+    int32_t nslices;
+    uint32_t slice_nbytes[H264E_MAX_SLICES];
     int32_t all_skipped;
     int32_t clusters_moved;             /* some macroblock's update would change the speculated mv_clusters state */
     int32_t overflow;
@@ -104,7 +108,9 @@ typedef struct
     uint32_t nbytes;
     int32_t all_skipped, clusters_moved, overflow;
     int32_t far_reads;
-    int32_t pad[2];
+    int32_t nslices;
+    uint32_t slice_nbytes[H264E_MAX_SLICES];
+    int32_t pad[1];
     int32_t done;                       /* written last: launch id when the job's results are complete, -launch id when it was aborted */
 } h264e_hostdone_t;
 
@@ -142,8 +148,11 @@ typedef struct
     int frame_slot;
     int first_row;                      /* macroblock rows above it are kept from the previous encode of this frame */
     int narrow;                         /* reference-window geometry the launch was made for (all jobs of a launch agree) */
-    int hdr_nbits;                      /* NAL header byte + slice header, MSB-aligned at bit hdr_nbits-1 */
+    int hdr_nal;                        /* NAL header byte; the kernel appends ue(first_mb_in_slice), then ... */
+    int hdr_nbits;                      /* ... hdr_nbits tail bits of the slice header, right-aligned in hdr_bits */
     uint64_t hdr_bits;
+    int nslices;                        /* >= 1 */
+    int16_t slice_row[H264E_MAX_SLICES + 1];    /* first macroblock row of every slice; slice_row[nslices] = nmby */
     mv32 clusters[2];                   /* speculated mv_clusters state for every macroblock of the frame ... */
     const mv32 *clusters_per_mb;        /* ... or, when not NULL, an exact per-macroblock trajectory [nmb][2] */
     uint16_t qdat[2][42];               /* quantizer tables (h264-lab.h:5839-5912), built by the host */

@@ -239,14 +239,16 @@ static size_t write_sps_pps(const seq_t *s, int pic_init_qp, uint8_t *d, nalu_cb
     return n;
 }
 
-/* h264-lab.h:4182-4333 encode_slice_header for KEY / P frames: NAL header byte + header as <= 64 bits */
-static void slice_header_bits(const seq_t *s, int key, int frame_num, int idr_pic_id, int qp, int pic_init_qp, int no_deblock,
-                              uint64_t *bits, int *nbits)
+/* h264-lab.h:4182-4333 encode_slice_header for KEY / P frames as a template: the NAL header byte, then (written by the
+ * kernel for every slice) ue(first_mb_in_slice), then the tail returned here.  nslices > 1: the row-band build's
+ * disable_deblocking_filter_idc = 2 (h264-lab.h:4315-4323) */
+static void slice_header_bits(const seq_t *s, int key, int frame_num, int idr_pic_id, int qp, int pic_init_qp, int no_deblock, int nslices,
+                              int *nal, uint64_t *bits, int *nbits)
 {
     hbits_t b;
+    const int idc = nslices > 1 ? (no_deblock ? 1 : 2) : no_deblock;
     memset(&b, 0, sizeof(b));
-    hb_put(&b, 8, key ? 0x65 : 0x61);
-    hb_ue(&b, 0);
+    *nal = key ? 0x65 : 0x61;
     hb_ue(&b, key ? SLICE_I : SLICE_P);
     hb_ue(&b, (uint32_t)(s->sps_id*4));
     hb_put(&b, 5, (uint32_t)(frame_num & 31));
@@ -254,10 +256,27 @@ static void slice_header_bits(const seq_t *s, int key, int frame_num, int idr_pi
     if (!key) hb_put(&b, 2, 0);
     if (key) hb_put(&b, 2, 0); else hb_put(&b, 1, 0);
     hb_se(&b, qp - pic_init_qp);
-    hb_ue(&b, (uint32_t)no_deblock);
+    hb_ue(&b, (uint32_t)idc);
     if (no_deblock != 1) hb_put(&b, 2, 3);
     *bits = b.acc;
     *nbits = b.n;
+}
+
+/* the slices of one frame as the kernel exports them (h264e_hip_result_t): start code + escaped payload for each, in order
+ * (h264-lab.h:6565-6569 concatenates the band outputs); cb as in nal_end.  Returns bytes written, 0 when cap is too small */
+static size_t emit_slices(uint8_t *d, size_t cap, const uint8_t *rb, const h264e_hip_result_t *r, nalu_cb_t cb, void *token)
+{
+    size_t pos = 0, off = 0;
+    int k;
+    for (k = 0; k < r->nslices; k++)
+    {
+        const size_t n = r->slice_nbytes[k], need = nal_escaped_size(rb + off, n);
+        if (pos + need > cap) return 0;
+        pos += nal_emit(d + pos, rb + off, n);
+        if (cb) cb(d + pos - (need - 4), (int)(need - 4), token);
+        off += (n + 15) & ~(size_t)15;
+    }
+    return pos;
 }
 
 /* ------------------------------------------------------------------ mv_clusters validation */
@@ -281,17 +300,29 @@ static void clusters_step(int32_t c[2], int32_t mv)
  * given: one pair for the whole frame (per_mb = 0) or one pair per macroblock.  traj (optional, [nmb][2])
  * receives the exact value in front of every macroblock.  Returns the first macroblock whose consumed,
  * rounded candidates differ from the exact ones, or -1.
+ * nslices > 1 (row bands): every band is encoded by a copy of the encoder that is thrown away (h264-lab.h:6526), so the
+ * walk restarts from the frame's start state at every band and `c` comes back unchanged.
  */
-static int clusters_walk(int32_t c[2], const h264e_hip_mbrec_t *rec, int nmb, const int32_t *used, int per_mb, int32_t *traj)
+static int clusters_walk(int32_t c[2], const h264e_hip_mbrec_t *rec, int nmbx, int nmby, int nslices, const int32_t *used, int per_mb, int32_t *traj)
 {
-    int i, first_bad = -1;
-    for (i = 0; i < nmb; i++)
+    const int32_t c0[2] = { c[0], c[1] };
+    int band, row0 = 0, first_bad = -1;
+    if (nslices < 1) nslices = 1;
+    for (band = 0; band < nslices; band++)
     {
-        const int32_t *u = per_mb ? used + 2*i : used;
-        if (traj) { traj[2*i] = c[0]; traj[2*i + 1] = c[1]; }
-        if (rec[i].used_cand && first_bad < 0 && (mvround(u[0]) != mvround(c[0]) || mvround(u[1]) != mvround(c[1]))) first_bad = i;
-        if (rec[i].type < 5) clusters_step(c, rec[i].mv0);
+        const int row1 = row0 + (nmby - row0)/(nslices - band);
+        int i;
+        c[0] = c0[0]; c[1] = c0[1];
+        for (i = row0*nmbx; i < row1*nmbx; i++)
+        {
+            const int32_t *u = per_mb ? used + 2*i : used;
+            if (traj) { traj[2*i] = c[0]; traj[2*i + 1] = c[1]; }
+            if (rec[i].used_cand && first_bad < 0 && (mvround(u[0]) != mvround(c[0]) || mvround(u[1]) != mvround(c[1]))) first_bad = i;
+            if (rec[i].type < 5) clusters_step(c, rec[i].mv0);
+        }
+        row0 = row1;
     }
+    if (nslices > 1) { c[0] = c0[0]; c[1] = c0[1]; }
     return first_bad;
 }
 
@@ -397,9 +428,10 @@ static void rc_frame_end(rc_t *rc, int nmb, int vbv_size_bytes, int desired_fram
  * chain, so this terminates.  run[k] is advanced to the state behind the frame; arr_out[k] (optional) receives
  * the per-macroblock array the final pass used (caller frees) or NULL.
  */
-static int step_exact(h264e_hip_pool_t *pool, int nchains, h264e_hip_task_t *tasks, int nmb, int32_t (*run)[2],
+static int step_exact(h264e_hip_pool_t *pool, int nchains, h264e_hip_task_t *tasks, int nmbx, int nmby, int32_t (*run)[2],
                       int32_t **arr_out, int *extra_passes)
 {
+    const int nmb = nmbx*nmby;
     int *flags = (int *)calloc(2*(size_t)nchains, sizeof(int));
     int32_t **arr = (int32_t **)calloc((size_t)nchains, sizeof(int32_t *));
     char *todo = (char *)calloc((size_t)nchains, 1);
@@ -431,7 +463,7 @@ static int step_exact(h264e_hip_pool_t *pool, int nchains, h264e_hip_task_t *tas
             }
             if (h264e_hip_read_mbrec(pool, k, tasks[k].frame_slot, rec)) goto done;
             cc[0] = run[k][0]; cc[1] = run[k][1];
-            bad = clusters_walk(cc, rec, nmb, arr[k] ? arr[k] : run[k], arr[k] != NULL, traj) >= 0;
+            bad = clusters_walk(cc, rec, nmbx, nmby, tasks[k].nslices, arr[k] ? arr[k] : run[k], arr[k] != NULL, traj) >= 0;
             if (!bad)
             {
                 run[k][0] = cc[0]; run[k][1] = cc[1];
@@ -468,6 +500,7 @@ typedef struct
     int frame_num, next_idr_pic_id, pic_init_qp;
     int32_t clusters[2];
     rc_t rc;
+    int slices;                             /* row-band slices per frame (H264E_set_slices), 0 / 1 = one */
 } henc_t;
 
 /* The reference API has no destructor and callers simply free() the blob, so nothing that needs
@@ -633,6 +666,14 @@ int H264E_init(H264E_persist_t *p, const H264E_create_param_t *par)
     return H264E_STATUS_SUCCESS;
 }
 
+int H264E_set_slices(H264E_persist_t *p, int nslices)
+{
+    henc_t *e = (henc_t *)p;
+    if (!e || e->magic != MAGIC || nslices < 0 || nslices > H264E_HIP_MAX_SLICES) return H264E_STATUS_BAD_PARAMETER;
+    e->slices = nslices;
+    return H264E_STATUS_SUCCESS;
+}
+
 void H264E_set_vbv_state(H264E_persist_t *p, int vbv_size_bytes, int vbv_fullness_bytes)
 {
     henc_t *e = (henc_t *)p;
@@ -691,28 +732,30 @@ int H264E_encode(H264E_persist_t *p, H264E_scratch_t *scratch, const H264E_run_p
     task.active = 1; task.frame_index = 0; task.frame_slot = 0;
     task.slice_type = key ? SLICE_I : SLICE_P;
     task.qp = qp; task.speed = opt->encode_speed;
+    task.nslices = e->slices > 1 ? imin(e->slices, e->seq.nmby) : 1;
     slice_header_bits(&e->seq, key, e->frame_num, e->next_idr_pic_id, qp, e->pic_init_qp,
-                      (opt->encode_speed == 8 || opt->encode_speed == 10), &task.hdr_bits, &task.hdr_nbits);
+                      (opt->encode_speed == 8 || opt->encode_speed == 10), task.nslices, &task.hdr_nal, &task.hdr_bits, &task.hdr_nbits);
     build_qdat(task.qdat, qp, !key);
 
     yuv[0] = in->yuv[0]; yuv[1] = in->yuv[1]; yuv[2] = in->yuv[2];
     if (h264e_hip_reset_results(m->pool, 0) || h264e_hip_upload_planes(m->pool, 0, yuv, in->stride)) return H264E_STATUS_BAD_ARGUMENT;
     {
         int32_t run[1][2] = { { e->clusters[0], e->clusters[1] } };
-        if (step_exact(m->pool, 1, &task, e->seq.nmb, run, NULL, NULL) || h264e_hip_result(m->pool, 0, 0, &res)) return H264E_STATUS_BAD_ARGUMENT;
+        if (step_exact(m->pool, 1, &task, e->seq.nmbx, e->seq.nmby, run, NULL, NULL) || h264e_hip_result(m->pool, 0, 0, &res)) return H264E_STATUS_BAD_ARGUMENT;
         e->clusters[0] = run[0][0]; e->clusters[1] = run[0][1];
     }
     if (res.nbytes > m->rbsp_cap) return H264E_STATUS_BAD_ARGUMENT;
     n = h264e_hip_read_rbsp(m->pool, 0, 0, m->rbsp, (uint32_t)m->rbsp_cap);
     if (n < 0) return H264E_STATUS_BAD_ARGUMENT;
-    if (out_pos + nal_escaped_size(m->rbsp, (size_t)n) > cap)
     {
-        snprintf(g_host_err, sizeof(g_host_err), "coded frame does not fit the scratch blob");
-        return H264E_STATUS_BAD_ARGUMENT;
+        const size_t w = (size_t)n == res.nbytes ? emit_slices(out + out_pos, cap - out_pos, m->rbsp, &res, opt->nalu_callback, opt->nalu_callback_token) : 0;
+        if (!w)
+        {
+            snprintf(g_host_err, sizeof(g_host_err), "coded frame does not fit the scratch blob");
+            return H264E_STATUS_BAD_ARGUMENT;
+        }
+        out_pos += w;
     }
-    out_pos += nal_emit(out + out_pos, m->rbsp, (size_t)n);
-    if (opt->nalu_callback)
-        opt->nalu_callback(out + out_pos - (nal_escaped_size(m->rbsp, (size_t)n) - 4), (int)(nal_escaped_size(m->rbsp, (size_t)n) - 4), opt->nalu_callback_token);
 
     rc_frame_end(&e->rc, e->seq.nmb, e->param.vbv_size_bytes, opt->desired_frame_bytes, (int)out_pos, key, res.all_skipped);
 
@@ -816,8 +859,15 @@ int H264E_clip_stamps(H264E_clip_t *c, unsigned long long *dst) { return c ? h26
 
 int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_bytes, int *frame_bytes, int profile, H264E_clip_stats_t *st)
 {
-    const int qp = c->par.qp, nmb = c->seq.nmb, G = c->gop_len, K = c->ring, no_deblock = (c->par.speed == 8 || c->par.speed == 10);
-    const int pic_init_qp = imax(imin(30, qp), qp);     /* qp_min = qp_max = qp (h264-lab.h:6768-6770) */
+    const int nmb = c->seq.nmb, G = c->gop_len, K = c->ring, no_deblock = (c->par.speed == 8 || c->par.speed == 10);
+    const int nslices = c->par.slices > 1 ? imin(imin(c->par.slices, H264E_HIP_MAX_SLICES), c->seq.nmby) : 1;
+    /* frame-level rate control (encode_app --kbps, minih264e_test.c:596-600: desired_frame_bytes = kbps*1000/8/30, QP 10..50):
+     * a frame's QP is a function of the byte count of the frame before it (h264-lab.h:5924-6141) and moves almost every
+     * frame, so frames cannot overlap: one frame per launch, the controller on the host between launches */
+    const int rc_on = c->par.kbps > 0, desired_frame_bytes = c->par.kbps*1000/8/30, qp_min = rc_on ? 10 : c->par.qp, qp_max = rc_on ? 50 : c->par.qp;
+    int qp = c->par.qp, rc_frame = -1;      /* rc_frame: the frame rc_frame_start has already run for (a re-encode keeps its QP) */
+    rc_t rcs;
+    const int pic_init_qp = imax(imin(30, qp_max), qp_min);     /* h264-lab.h:6768-6770 */
     const int idr_state = c->par.first_idr_pic_id_state & 1;
     h264e_hip_task_t *tasks = (h264e_hip_task_t *)calloc((size_t)K, sizeof(*tasks));
     int *flags = (int *)calloc(2*(size_t)K, sizeof(int));
@@ -843,6 +893,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
     memset(&stats, 0, sizeof(stats));
     g_host_err[0] = 0;
     if (!tasks || !flags || !used || !rec || !traj || !rbsp) goto done;
+    memset(&rcs, 0, sizeof(rcs));
     build_qdat(qdat_i, qp, 0);
     build_qdat(qdat_p, qp, 1);
     h264e_hip_profile(c->pool, profile);
@@ -850,10 +901,17 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
 
     while (n < c->nframes)
     {
-        const int F = imin(K - 1, c->nframes - n);
+        const int F = rc_on ? 1 : imin(K - 1, c->nframes - n);
         int nvalid = 0;
         t0 = now_ms();
         memset(tasks, 0, sizeof(*tasks)*(size_t)K);
+        if (rc_on && rc_frame != n)
+        {
+            const int key = (n % G) == 0;
+            qp = rc_frame_start(&rcs, c->par.gop, nmb, c->par.vbv_size_bytes, desired_frame_bytes, qp_min, qp_max, key);
+            build_qdat(key ? qdat_i : qdat_p, qp, !key);
+            rc_frame = n;
+        }
         for (i = 0; i < F; i++)
         {
             h264e_hip_task_t *t = tasks + i;
@@ -862,7 +920,8 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             t->slice_type = key ? SLICE_I : SLICE_P;
             t->qp = qp; t->speed = c->par.speed;
             /* frame_num restarts at every key frame; idr_pic_id toggles with every key frame (h264-lab.h:6774-6775) */
-            slice_header_bits(&c->seq, key, f % G, (idr_state ^ ((f/G + 1) & 1)), qp, pic_init_qp, no_deblock, &t->hdr_bits, &t->hdr_nbits);
+            t->nslices = nslices;
+            slice_header_bits(&c->seq, key, f % G, (idr_state ^ ((f/G + 1) & 1)), qp, pic_init_qp, no_deblock, nslices, &t->hdr_nal, &t->hdr_bits, &t->hdr_nbits);
             memcpy(t->qdat, key ? qdat_i : qdat_p, sizeof(t->qdat));
             t->stream_mode = 1; t->slot = f % K;
             t->ref_slot = key ? -1 : (f - 1) % K;
@@ -907,7 +966,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             {
                 /* exact walk: does every consumed (rounded) candidate equal what the kernel was given? */
                 int32_t cc[2] = { state[0], state[1] };
-                const int first_bad = clusters_walk(cc, h264e_hip_stream_mbrec(c->pool, slot), nmb, per_mb ? first_arr : used[i], per_mb, traj);
+                const int first_bad = clusters_walk(cc, h264e_hip_stream_mbrec(c->pool, slot), c->seq.nmbx, c->seq.nmby, nslices, per_mb ? first_arr : used[i], per_mb, traj);
                 const int bad = first_bad >= 0;
                 if (bad)
                 {
@@ -929,11 +988,17 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             t0 = now_ms();
             {
                 const uint8_t *rb = h264e_hip_stream_rbsp(c->pool, slot);
-                size_t start = pos, need = nal_escaped_size(rb, r1.nbytes) + (key ? 64 : 0);
-                if (pos + need > cap) { snprintf(g_host_err, sizeof(g_host_err), "output buffer too small"); (void)h264e_hip_stream_abort(c->pool); (void)h264e_hip_sync(c->pool); goto done; }
-                if (key) pos += write_sps_pps(&c->seq, pic_init_qp, out + pos, NULL, NULL);
-                pos += nal_emit(out + pos, rb, r1.nbytes);
+                size_t start = pos, w;
+                if (key)
+                {
+                    if (pos + 64 > cap) { snprintf(g_host_err, sizeof(g_host_err), "output buffer too small"); (void)h264e_hip_sync(c->pool); goto done; }
+                    pos += write_sps_pps(&c->seq, pic_init_qp, out + pos, NULL, NULL);
+                }
+                w = emit_slices(out + pos, cap - pos, rb, &r1, NULL, NULL);
+                if (!w) { snprintf(g_host_err, sizeof(g_host_err), "output buffer too small"); (void)h264e_hip_stream_abort(c->pool); (void)h264e_hip_sync(c->pool); goto done; }
+                pos += w;
                 if (frame_bytes) frame_bytes[f] = (int)(pos - start);
+                if (rc_on) rc_frame_end(&rcs, nmb, c->par.vbv_size_bytes, desired_frame_bytes, (int)(pos - start), key, r1.all_skipped);
             }
             stats.assemble_ms += now_ms() - t0;
             nvalid++;

@@ -103,6 +103,8 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
                 const GLOBAL_AS h264e_frameout_t &F = C.fout[T.frame_slot];
                 GLOBAL_AS h264e_hostdone_t *hd = (GLOBAL_AS h264e_hostdone_t *)T.host_done;
                 hd->nbytes = F.nbytes; hd->all_skipped = F.all_skipped;
+                hd->nslices = F.nslices;
+                for (int k = 0; k < H264E_MAX_SLICES; k++) hd->slice_nbytes[k] = F.slice_nbytes[k];
                 hd->clusters_moved = F.clusters_moved; hd->overflow = F.overflow; hd->far_reads = F.far_reads;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                 /* system scope: the host reads these */
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -116,12 +118,16 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
     if (row < T.first_row) return;          /* kept from the previous encode of this frame (its counter already says complete) */
     row_begin(L, G, C, T, row);
     int seen = 0, seen_dep = 0;
+    int row0 = 0, row1 = G.nmby;            /* the slice (row band) this row belongs to */
+    for (int k = 0; k < T.nslices; k++)
+        if (row >= T.slice_row[k] && row < T.slice_row[k + 1]) { row0 = T.slice_row[k]; row1 = T.slice_row[k + 1]; }
+    row0 = uni(row0); row1 = uni(row1);
     constexpr int DEP_ROWS = NARROW ? H264E_NARROW_DEP_ROWS : H264E_DEP_ROWS, DEP_COLS = NARROW ? H264E_NARROW_DEP_COLS : H264E_DEP_COLS;
     const int dep_row = imin(row + DEP_ROWS, G.nmby - 1);
     for (int x = 0; x < G.nmbx; x++)
     {
         /* consumer: relaxed sc1 polls, then sc1 loads of everything handed over */
-        const int need = row > 0 ? imin(x + 2, G.nmbx) : 0;
+        const int need = row > row0 ? imin(x + 2, G.nmbx) : 0;
         const int need_dep = T.dep_progress ? imin(x + DEP_COLS, G.nmbx) : 0;     /* temporal wavefront: h264e_dev.h */
         int st = 0;
         /* the abort word lives in host memory (one PCIe read): look at it every 8th macroblock only */
@@ -150,7 +156,7 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
             return;
         }
         STAMP(L, 13);
-        row_step<NARROW>(L, G, C, T, row, x);
+        row_step<NARROW>(L, G, C, T, row, x, row0, row1);
         {
             /* a far reference read of this macroblock waited in vain (rv_wait_rect): what it encoded is not trustworthy */
             const int ff = uni(L.far_fail);
@@ -546,7 +552,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         d.active = t.active;
         if (!t.active) continue;
         if (t.frame_index < 0 || t.frame_index >= p->frames_resident || t.frame_slot < 0 || t.frame_slot >= p->slots ||
-            t.qp < 10 || t.qp > 51 || t.hdr_nbits < 8 || t.hdr_nbits > 64)
+            t.qp < 10 || t.qp > 51 || t.hdr_nbits < 0 || t.hdr_nbits > 56 || t.nslices < 0 || t.nslices > H264E_MAX_SLICES || t.nslices > G.nmby)
         {
             free(host);
             FAIL("submit: bad task for chain %d", c);
@@ -596,7 +602,14 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         d.narrow = t.stream_mode && t.narrow_window;
         any_narrow |= d.narrow;
         any_wide |= !d.narrow;
-        d.hdr_nbits = t.hdr_nbits; d.hdr_bits = t.hdr_bits;
+        d.hdr_nal = t.hdr_nal; d.hdr_nbits = t.hdr_nbits; d.hdr_bits = t.hdr_bits;
+        {
+            /* row bands exactly as the reference splits them (h264-lab.h:6530): mby += (nmby - mby)/(nthreads - ithr) */
+            int mby = 0;
+            d.nslices = t.nslices > 1 ? t.nslices : 1;
+            for (int k = 0; k < d.nslices; k++) { d.slice_row[k] = (int16_t)mby; mby += (G.nmby - mby)/(d.nslices - k); }
+            d.slice_row[d.nslices] = (int16_t)G.nmby;
+        }
         d.clusters[0] = t.mv_clusters[0]; d.clusters[1] = t.mv_clusters[1];
         d.clusters_per_mb = 0;
         if (t.mv_clusters_per_mb)
@@ -635,7 +648,10 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         {
             RowLds *L = (RowLds *)calloc(1, sizeof(RowLds));
             row_begin(*L, G, C, T, row);
-            for (int x = 0; x < G.nmbx; x++) { row_prefetch(*L, G, T, row, x); if (T.narrow) row_step<true>(*L, G, C, T, row, x); else row_step<false>(*L, G, C, T, row, x); }
+            int row0 = 0, row1 = G.nmby;
+            for (int k = 0; k < T.nslices; k++)
+                if (row >= T.slice_row[k] && row < T.slice_row[k + 1]) { row0 = T.slice_row[k]; row1 = T.slice_row[k + 1]; }
+            for (int x = 0; x < G.nmbx; x++) { row_prefetch(*L, G, T, row, x); if (T.narrow) row_step<true>(*L, G, C, T, row, x, row0, row1); else row_step<false>(*L, G, C, T, row, x, row0, row1); }
             row_end(*L, G, C, row);
             free(L);
         }
@@ -645,6 +661,8 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             export_frame(G, C, T);
             const h264e_frameout_t &F = C.fout[T.frame_slot];
             T.host_done->nbytes = F.nbytes; T.host_done->all_skipped = F.all_skipped;
+            T.host_done->nslices = F.nslices;
+            for (int k = 0; k < H264E_MAX_SLICES; k++) T.host_done->slice_nbytes[k] = F.slice_nbytes[k];
             T.host_done->clusters_moved = F.clusters_moved; T.host_done->overflow = F.overflow; T.host_done->far_reads = F.far_reads;
             T.host_done->done = T.launch_id;
         }
@@ -708,7 +726,12 @@ extern "C" int h264e_hip_stream_done(h264e_hip_pool_t *p, int slot, h264e_hip_re
     if (v == -p->slot_launch[slot]) return 2;               /* the job was aborted */
     if (v != p->slot_launch[slot]) return 0;                /* not yet */
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    if (res) { res->nbytes = d->nbytes; res->all_skipped = d->all_skipped; res->clusters_moved = d->clusters_moved; res->overflow = d->overflow; res->far_reads = d->far_reads; }
+    if (res)
+    {
+        res->nbytes = d->nbytes; res->all_skipped = d->all_skipped; res->clusters_moved = d->clusters_moved; res->overflow = d->overflow; res->far_reads = d->far_reads;
+        res->nslices = d->nslices;
+        for (int k = 0; k < H264E_HIP_MAX_SLICES; k++) res->slice_nbytes[k] = d->slice_nbytes[k];
+    }
     return 1;
 }
 
@@ -754,6 +777,8 @@ extern "C" int h264e_hip_result(h264e_hip_pool_t *p, int chain, int slot, h264e_
     HIPCHK(hipMemcpy(&f, p->chains_host[chain].fout + slot, sizeof(f), hipMemcpyDeviceToHost));
 #endif
     res->nbytes = f.nbytes; res->all_skipped = f.all_skipped; res->clusters_moved = f.clusters_moved; res->overflow = f.overflow; res->far_reads = f.far_reads;
+    res->nslices = f.nslices;
+    for (int k = 0; k < H264E_HIP_MAX_SLICES; k++) res->slice_nbytes[k] = f.slice_nbytes[k];
     return 0;
 }
 
@@ -796,6 +821,8 @@ extern "C" int h264e_hip_read_chain(h264e_hip_pool_t *p, int chain, int nslots, 
     for (int i = 0; i < nslots; i++)
     {
         res[i].nbytes = f[i].nbytes; res[i].all_skipped = f[i].all_skipped; res[i].clusters_moved = f[i].clusters_moved; res[i].overflow = f[i].overflow;
+        res[i].far_reads = f[i].far_reads; res[i].nslices = f[i].nslices;
+        for (int k = 0; k < H264E_HIP_MAX_SLICES; k++) res[i].slice_nbytes[k] = f[i].slice_nbytes[k];
         offsets[i] = f[i].offset;
     }
     free(f);

@@ -34,8 +34,14 @@ typedef struct
     int slice_type;             /* 0 = P, 2 = I   (h264-lab.h:3203-3204) */
     int qp;                     /* frame QP, 10..51 */
     int speed;                  /* H264E_run_param_t.encode_speed (h264-lab.h:181) */
-    int hdr_nbits;              /* NAL header byte + slice header bits (h264-lab.h:4182-4333), <= 64 */
-    uint64_t hdr_bits;          /* right-aligned */
+    /* slice header (h264-lab.h:4182-4333) as a template: NAL header byte, then ue(first_mb_in_slice) -- written by the kernel
+     * for every slice -- then `hdr_nbits` <= 56 tail bits (slice_type ... deblocking fields), right-aligned in hdr_bits */
+    int hdr_nal;
+    int hdr_nbits;
+    uint64_t hdr_bits;
+    /* row-band slices (h264-lab.h:6511-6574, the reference's H264E_MAX_THREADS build): 0 / 1 = one slice per frame; N > 1 =
+     * N slices of consecutive macroblock rows, split like the reference (h264-lab.h:6530); <= H264E_HIP_MAX_SLICES */
+    int nslices;
     int32_t mv_clusters[2];     /* speculated enc->mv_clusters for the whole frame (h264-lab.h:766) */
     const int32_t *mv_clusters_per_mb;  /* optional HOST array [nmb][2]: exact per-macroblock values (re-encode path) */
     uint16_t qdat[2][42];       /* quantizer tables of rc_set_qp (h264-lab.h:5839-5912) */
@@ -51,9 +57,13 @@ typedef struct
     int narrow_window;
 } h264e_hip_task_t;
 
+#define H264E_HIP_MAX_SLICES 16
+
 typedef struct
 {
-    uint32_t nbytes;            /* RBSP bytes of the slice NAL (header byte included, no start code, no escapes) */
+    uint32_t nbytes;            /* bytes of the frame's slice RBSPs as exported: slice k starts at the sum of the 16-byte-rounded sizes before it */
+    int nslices;
+    uint32_t slice_nbytes[H264E_HIP_MAX_SLICES];   /* RBSP bytes of each slice NAL (header byte included, no start code, no escapes) */
     int all_skipped;            /* every macroblock was skipped (rc_frame_end's skip_flag, h264-lab.h:6596) */
     int clusters_moved;         /* the speculated mv_clusters state is not a fixed point of this frame */
     int overflow;               /* a bit buffer overflowed: the result is invalid */

@@ -102,6 +102,11 @@ void H264E_set_vbv_state(H264E_persist_t *enc, int vbv_size_bytes, int vbv_fulln
 /* The reference API has no destructor: device resources of an encoder are released when the
  * same persist blob is initialised again, at process exit, or explicitly here. */
 void H264E_close(H264E_persist_t *enc);
+/* Row-band slices per frame for the drop-in encoder: the reference selects this through H264E_create_param_t.max_threads,
+ * a field that only exists when it is compiled with -DH264E_MAX_THREADS=N (h264-lab.h:142-170, :6511-6574) and that changes
+ * the struct ABI; this library keeps the default ABI and takes the number here instead.  0 / 1 = one slice per frame,
+ * 2..16 = N slices (deblocking idc 2, contexts / availability / mv_clusters restarted per slice).  Call after H264E_init. */
+int  H264E_set_slices(H264E_persist_t *enc, int nslices);
 /* Select the HIP device used by subsequent H264E_init calls of this process (default 0 / $H264E_DEVICE). */
 void H264E_set_device(int device);
 /* Last device-side error text (empty when none). */
@@ -109,7 +114,8 @@ const char *H264E_last_error(void);
 
 /* Whole-clip streaming encode: consecutive frames run as a temporal wavefront inside one
  * kernel launch, finished frames are validated and NAL-assembled by the host while the launch runs (DESIGN.md
- * sections 4-5).  Bit-identical to feeding the frames one by one to H264E_encode.  Constant QP only. */
+ * sections 4-5).  Bit-identical to feeding the frames one by one to H264E_encode.  With rate control (kbps) a frame's QP depends on the size
+ * of the frame before it, so frames cannot overlap and run one per launch. */
 typedef struct
 {
     int width, height, gop, qp, speed;
@@ -118,6 +124,8 @@ typedef struct
     int max_chains;                         /* frames in flight per launch (0 = default 96) */
     int first_idr_pic_id_state;             /* enc->next_idr_pic_id before the first frame (0 for a fresh stream) */
     int32_t mv_clusters_in[2];              /* enc->mv_clusters before the first frame (0,0 for a fresh stream) */
+    int slices;                             /* row-band slices per frame: 0 / 1 = one; N = the reference's H264E_MAX_THREADS build with --threads N */
+    int kbps;                               /* 0 = constant QP `qp`; > 0 = frame-level rate control as encode_app --kbps (frames then run one per launch) */
 } H264E_clip_param_t;
 
 typedef struct

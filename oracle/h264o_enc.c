@@ -1140,6 +1140,8 @@ void h264o_close(h264o_enc_t *e)
     free(e);
 }
 
+int h264o_get_qp(const h264o_enc_t *e) { return e->qp; }     /* QP of the last encoded frame (rate control tests) */
+
 void h264o_get_chain(const h264o_enc_t *e, h264o_chain_t *c)
 {
     c->mv_clusters[0] = e->clusters[0]; c->mv_clusters[1] = e->clusters[1]; c->next_idr_pic_id = e->next_idr_pic_id;

@@ -76,3 +76,61 @@ def test_unsupported_options_are_refused():
         cp = P.CreateParam(width=64, height=48, gop=2, const_input_flag=1, **kw)
         assert L.H264E_init(buf, C.byref(cp)) == 2
     assert L.H264E_init(None, None) == 1
+
+
+@pytest.mark.parametrize("name,w,h,n,gop,qp,slices,kbps", [
+    ("synth", 352, 288, 4, 30, 26, 2, 0), ("synth", 352, 288, 4, 30, 26, 4, 0), ("pan", 352, 288, 5, 30, 26, 3, 0),
+    ("noise", 176, 144, 3, 2, 30, 8, 0), ("synth", 200, 120, 4, 30, 26, 2, 0), ("synth", 352, 288, 4, 30, 26, 4, 300)])
+def test_row_band_slices_match_oracle(name, w, h, n, gop, qp, slices, kbps):
+    """--threads N of the reference's H264E_MAX_THREADS build = N row-band slices (h264-lab.h:6511-6574): per-slice headers with
+    first_mb_in_slice, deblocking idc 2, availability / contexts / mv_clusters restarted per slice -- drop-in API and clip encoder"""
+    P = pkg.load_pkg()
+    c = clips.make(name, w, h, n)
+    want, sizes = oracle_lib.encode_clip(c, w, h, gop=gop, qp=qp, kbps=kbps, slices=slices)
+    e = P.Encoder(w, h, gop=gop, qp=qp, kbps=kbps, lib=pkg.EMU_LIB, slices=slices)
+    got = [e.encode(c[t]) for t in range(n)]
+    e.close()
+    assert [len(x) for x in got] == sizes and b"".join(got) == want
+    if not kbps:
+        ce = P.ClipEncoder(w, h, n, gop=gop, qp=qp, lib=pkg.EMU_LIB, slices=slices)
+        ce.upload(c)
+        out, fs, _ = ce.encode()
+        ce.close()
+        assert out == want and fs == sizes
+
+
+def test_nalu_callback_sees_every_nal():
+    """h264-lab.h:4014-4018: nal_end hands EVERY NAL to run_param.nalu_callback -- SPS and PPS on key frames, then each slice --
+    pointer behind the start code, escaped length; the callback bytes, re-framed, are the coded data"""
+    import ctypes as C
+    P = pkg.load_pkg()
+    w, h, n = 64, 48, 3
+    c = clips.make("synth", w, h, n)
+    e = P.Encoder(w, h, gop=2, qp=26, lib=pkg.EMU_LIB, slices=3)
+    seen = []
+    from h264_lab_amd.binding import NALU_CB
+    cb = NALU_CB(lambda p, size, tok: seen.append(C.string_at(p, size)))
+    e.rp.nalu_callback = cb
+    for t in range(n):
+        seen.clear()
+        data = e.encode(c[t])
+        key = t % 2 == 0
+        assert len(seen) == (2 if key else 0) + 3
+        assert b"".join(b"\x00\x00\x00\x01" + s for s in seen) == data
+        if key:
+            assert seen[0][0] == 0x67 and seen[1][0] == 0x68
+        assert all(s[0] in (0x65, 0x61) for s in seen[-3:])
+    e.close()
+
+
+@pytest.mark.parametrize("name,w,h,n,gop,kbps,slices", [("synth", 352, 288, 6, 30, 500, 0), ("synth", 176, 144, 8, 4, 100, 0), ("pan", 352, 288, 5, 30, 300, 3)])
+def test_clip_encoder_rate_control(name, w, h, n, gop, kbps, slices):
+    """frame-level rate control (--kbps) through the clip encoder: one frame per launch, the controller between launches"""
+    P = pkg.load_pkg()
+    c = clips.make(name, w, h, n)
+    want, sizes = oracle_lib.encode_clip(c, w, h, gop=gop, kbps=kbps, slices=slices)
+    ce = P.ClipEncoder(w, h, n, gop=gop, lib=pkg.EMU_LIB, slices=slices, kbps=kbps)
+    ce.upload(c)
+    out, fs, _ = ce.encode()
+    ce.close()
+    assert out == want and fs == sizes

@@ -1,0 +1,44 @@
+"""GPU: the HIP path against FULL-LENGTH streams of the reference encoder (tests/golden/golden_big.json, produced by
+tests/golden/make_golden_big.py from oracle/_ref): the whole 600-frame 1080p bench stream with all its mis-speculation
+relaunches, 300-frame CIF (BASELINE configs[0]/[1] stand-ins), 4K, 8K, rate control and row-band multi-slice streams."""
+import hashlib
+import json
+import os
+
+import pytest
+
+import pkg
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN_BIG = json.load(open(os.path.join(HERE, "golden", "golden_big.json")))
+
+
+def _flags(s):
+    t = s.split()
+    d = dict(zip(t[0::2], t[1::2]))
+    return dict(gop=int(d.get("--gop", 20)), qp=int(d.get("--qp", 33)), speed=int(d.get("--speed", 0)), kbps=int(d.get("--kbps", 0)),
+                slices=int(d.get("--threads", 0)))
+
+
+@pytest.fixture(scope="module")
+def P():
+    p = pkg.load_pkg()
+    L = p.load()
+    assert L.h264e_hip_device_count() > 0, "no HIP device visible"
+    return p
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN_BIG))
+def test_full_length_stream_matches_reference(P, name):
+    """streaming clip encoder (input generated in HBM by the synth_v1 kernel, md5 of the generator pinned elsewhere)"""
+    g = GOLDEN_BIG[name]
+    f = _flags(g["flags"])
+    ce = P.ClipEncoder(g["w"], g["h"], g["frames"], gop=f["gop"], qp=f["qp"], speed=f["speed"], slices=f["slices"], kbps=f["kbps"])
+    ce.generate_synth()
+    out, sizes, st = ce.encode()
+    ce.close()
+    assert sizes == g["frame_bytes"]
+    assert len(out) == g["bytes"] and hashlib.md5(out).hexdigest() == g["md5"]
+    if name == "bench_1080p_600":
+        assert st.reencoded_gops >= 10, "the bench stream no longer exercises the relaunch path"

@@ -196,3 +196,41 @@ def test_error_codes(P):
         e.encode(f, frame_type=2)
     assert len(e.encode(f)) > 0
     e.close()
+
+
+@pytest.mark.parametrize("name,w,h,n,gop,qp,slices,kbps", [
+    ("synth", 352, 288, 6, 30, 26, 2, 0), ("synth", 352, 288, 6, 30, 26, 4, 0), ("pan", 352, 288, 6, 30, 26, 3, 0),
+    ("noise", 176, 144, 4, 2, 30, 8, 0), ("synth", 200, 120, 5, 30, 26, 2, 0), ("extremes", 176, 144, 4, 30, 20, 5, 0),
+    ("synth", 352, 288, 6, 30, 26, 4, 300), ("pan", 352, 288, 8, 30, 30, 8, 0), ("synth", 1920, 1080, 4, 30, 26, 16, 0)])
+def test_row_band_slices_match_oracle(P, name, w, h, n, gop, qp, slices, kbps):
+    """multi-slice (the reference's H264E_MAX_THREADS build, --threads N): drop-in API and streaming clip encoder"""
+    c = clips.make(name, w, h, n)
+    want, sizes = oracle_lib.encode_clip(c, w, h, gop=gop, qp=qp, kbps=kbps, slices=slices)
+    e = P.Encoder(w, h, gop=gop, qp=qp, kbps=kbps, slices=slices)
+    got = [e.encode(c[t]) for t in range(n)]
+    e.close()
+    assert [len(x) for x in got] == sizes and b"".join(got) == want
+    ce = P.ClipEncoder(w, h, n, gop=gop, qp=qp, slices=slices, kbps=kbps)
+    ce.upload(c)
+    out, fs, _ = ce.encode()
+    ce.close()
+    assert out == want and fs == sizes
+
+
+@pytest.mark.parametrize("w,h,n,dy", [(1920, 1080, 4, 40), (1920, 1080, 3, 96), (3840, 2160, 3, 64)])
+def test_large_vertical_motion_far_reads(P, w, h, n, dy):
+    """vertical pan of 40..96 samples per frame through the streaming encoder: vectors leave the LDS window, so reference
+    reads take the HBM path with its dynamic wait on rows of the frame that is still being encoded (rv_wait_rect) -- the one
+    wait that can target a workgroup later in the dispatch order.  Must equal the oracle byte for byte."""
+    big = synth.frame(w, h + dy * n + 16, 0)
+    ybig = big[: w * (h + dy * n + 16)].reshape(h + dy * n + 16, w)
+    c = np.empty((n, w * h * 3 // 2), np.uint8)
+    for t in range(n):
+        c[t, : w * h] = ybig[dy * t : dy * t + h].ravel()
+        c[t, w * h :] = 128
+    want, sizes = oracle_lib.encode_clip(c, w, h, gop=30, qp=30)
+    ce = P.ClipEncoder(w, h, n, gop=30, qp=30)
+    ce.upload(c)
+    out, fs, _ = ce.encode()
+    ce.close()
+    assert fs == sizes and out == want

@@ -80,3 +80,41 @@ def test_gop_chain_handoff():
         ref = whole[off : off + sum(sizes[k * gop : (k + 1) * gop])]
         off += len(ref)
         assert part == ref, "GOP %d differs" % k
+
+
+GOLDEN_BIG = json.load(open(os.path.join(HERE, "golden", "golden_big.json")))
+
+
+def _flags_big(s):
+    t = s.split()
+    d = dict(zip(t[0::2], t[1::2]))
+    return dict(gop=int(d.get("--gop", 20)), qp=int(d.get("--qp", 33)), speed=int(d.get("--speed", 0)), kbps=int(d.get("--kbps", 0)),
+                slices=int(d.get("--threads", 0)))
+
+
+# full-length streams of the REFERENCE (tests/golden/make_golden_big.py).  The CPU suite checks the ones the oracle finishes in
+# seconds; the long ones (1080p x 600, 4K, 8K) are checked against the HIP path in tests/test_gpu_golden_big.py.
+@pytest.mark.parametrize("name", ["cif_30_thr2", "cif_30_thr4", "cif_60_kbps", "cif_300_gop30", "cif_300_intra"])
+def test_oracle_matches_reference_full_length(name):
+    g = GOLDEN_BIG[name]
+    c = oracle_lib.synth_c(g["w"], g["h"], g["frames"])
+    assert hashlib.md5(c.tobytes()).hexdigest() == g["input_md5"]
+    data, sizes = oracle_lib.encode_clip(c, g["w"], g["h"], **_flags_big(g["flags"]))
+    assert sizes == g["frame_bytes"]
+    assert hashlib.md5(data).hexdigest() == g["md5"]
+
+
+@pytest.mark.skipif(not os.path.exists(oracle_lib.REF_APP_THR), reason="compiled multi-slice reference (oracle/_ref) not present")
+@pytest.mark.parametrize("slices,flags", [(2, "--qp 26 --gop 30"), (3, "--qp 40 --gop 2"), (5, "--qp 18 --gop 30 --speed 2"), (8, "--kbps 200 --gop 30")])
+def test_oracle_row_bands_vs_compiled_reference(tmp_path, slices, flags):
+    """side-by-side with the reference built with -DH264E_MAX_THREADS=8 (oracle/_ref/encode_app_ref_thr) on a fresh clip"""
+    w, h, n = 176, 144, 5
+    c = clips.make("pan", w, h, n) if slices == 3 else synth.clip(w, h, n, seed=slices)
+    yuv = tmp_path / ("c_%dx%d.yuv" % (w, h))
+    c.tofile(yuv)
+    out = tmp_path / "o.264"
+    subprocess.run([oracle_lib.REF_APP_THR, "--input", str(yuv), "--output", str(out)] + flags.split() + ["--threads", str(slices)], check=True, capture_output=True)
+    kw = _flags_big(flags)
+    kw["slices"] = slices
+    data, _ = oracle_lib.encode_clip(c, w, h, **kw)
+    assert data == out.read_bytes()
