@@ -149,6 +149,8 @@ struct RefView
     int vw, vh;                 /* valid columns / rows of the window (h264e_dev.h: wide 64 x 64, narrow 53 x 52) */
     int *far;                   /* LDS counter of accesses that had to leave the window */
     int *fail;                  /* LDS flag: a dynamic wait of this row gave up (spin bound expired): the row must stop and report */
+    const int16_t *slice_row;   /* LDS: first macroblock row of every slice of the frame, slice_row[nslices] = nmby */
+    int nslices;
 };
 
 /* wave-uniform: does the sample rectangle [x0,x1] x [y0,y1] lie inside the window? */
@@ -169,13 +171,15 @@ DEV const lu8 *rv_ptr(const RefView &V, int x, int y) { return V.win + (y - V.wy
  * (12 - lag) dispatch keys = about (12 - lag)*(nmby+1)/2 workgroups ahead (8K: 1080), fewer than the ~2000 workgroups the
  * dispatcher keeps resident beyond the oldest unfinished one -- and if that ever fails the bound below reports it.
  */
-DEV void rv_wait_rect(const RefView &V, int x1, int y1)
+DEV bool rv_slice_last(const RefView &V, int Y)           /* is macroblock row Y the last row of its slice (nothing below filters it)? */
 {
-    if (V.far) *V.far += 1;
+    for (int k = 1; k <= V.nslices; k++) if (V.slice_row[k] == Y + 1) return true;
+    return false;
+}
+/* one wait: row `drow` of the producing frame must have published `need` macroblocks */
+DEV void rv_wait_row(const RefView &V, int drow, int need)
+{
 #ifndef H264E_EMU
-    if (!V.dep) return;
-    const int X = imin(imax(x1, 0), V.P.w - 1) >> 4, Y = imin(imax(y1, 0), V.P.h - 1) >> 4;
-    const int drow = imin(Y + 1, V.nmby - 1), need = imin(X + 2, V.nmbx);
     const GLOBAL_AS int *flag = V.dep + drow;
     unsigned spins = 0;
     for (;;)
@@ -189,9 +193,28 @@ DEV void rv_wait_rect(const RefView &V, int x1, int y1)
         if (++spins > (1u << 24)) { if (V.fail) *V.fail = -1; break; }
         __builtin_amdgcn_s_sleep(8);
     }
+#else
+    (void)V; (void)drow; (void)need;
+#endif
+}
+/* sample rows y0..y1, columns up to x1.  Inside one slice the lowest macroblock row is the last to become final; row bands of
+ * different slices advance independently, so every slice the rectangle touches is waited for at its lowest row inside it. */
+DEV void rv_wait_rect(const RefView &V, int y0, int x1, int y1)
+{
+    if (V.far) *V.far += 1;
+#ifndef H264E_EMU
+    if (!V.dep) return;
+    const int X = imin(imax(x1, 0), V.P.w - 1) >> 4, Ya = imin(imax(y0, 0), V.P.h - 1) >> 4, Yb = imin(imax(y1, 0), V.P.h - 1) >> 4;
+    const int need = imin(X + 2, V.nmbx);
+    for (int Y = Ya; Y <= Yb; Y++)
+    {
+        const bool last = rv_slice_last(V, Y);
+        if (last) rv_wait_row(V, Y, need);
+        else if (Y == Yb) rv_wait_row(V, Y + 1, need);
+    }
     consumer_acquire();
 #else
-    (void)V; (void)x1; (void)y1;
+    (void)y0; (void)x1; (void)y1;
 #endif
 }
 
@@ -243,7 +266,7 @@ DEV int wave_sad_ref(const RefView &R, int x0, int y0, const uint8_t *b, int w, 
             return (int)sad4_u8(lds32u(base + r*WIN_STRIDE + 4*c), lds32(b + 16*r + 4*c), 0);
         });
     }
-    rv_wait_rect(R, x0 + w - 1, y0 + h - 1);
+    rv_wait_rect(R, y0, x0 + w - 1, y0 + h - 1);
     return wave_sum([&](int l) -> int {
         if (l >= n) return 0;
         int r = l >> (g >> 1), c = l & (g - 1);              /* g is 2 or 4 */
@@ -263,7 +286,7 @@ DEV int wave_sad_ref_q(const RefView &R, int x0, int y0, const uint8_t *b, int s
         }, sad4);
     } else
     {
-        rv_wait_rect(R, x0 + 15, y0 + 15);
+        rv_wait_rect(R, y0, x0 + 15, y0 + 15);
         wave_sum4([&](int l, int *v) {
             int r = l >> 2, c = l & 3;
             v[(r >> 3)*2 + (c >> 1)] = (int)sad4_u8(ref_load4(R.P, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
@@ -452,7 +475,7 @@ DEV void wave_interp_luma(const RefView &R, int bx, int by, mv32 mv, int w, int 
 {
     const int g = w >> 2, n = g*h, ix = bx + (mvx(mv) >> 2), iy = by + (mvy(mv) >> 2), fx = mvx(mv) & 3, fy = mvy(mv) & 3;
     const bool inside = rv_inside_interp(R, ix, iy, w, h);
-    if (!inside) rv_wait_rect(R, ix + w + 3, iy + h + 2);
+    if (!inside) rv_wait_rect(R, iy - 2, ix + w + 3, iy + h + 2);
     WAVE_FOR(l)
     {
         if (l < n)
@@ -504,7 +527,7 @@ DEV void wave_interp_chroma(const RefView &RL, const Plane &RU, const Plane &RV,
 {
     {   /* luma-sample rectangle this chroma block corresponds to: inside the window it is covered by the row loop's lag */
         const int lx0 = 2*(cx + (mvx(mv) >> 3)), ly0 = 2*(cy + (mvy(mv) >> 3));
-        if (!rv_inside(RL, lx0, ly0, lx0 + 2*w + 3, ly0 + 2*h + 3)) rv_wait_rect(RL, lx0 + 2*w + 3, ly0 + 2*h + 3);
+        if (!rv_inside(RL, lx0, ly0, lx0 + 2*w + 3, ly0 + 2*h + 3)) rv_wait_rect(RL, ly0, lx0 + 2*w + 3, ly0 + 2*h + 3);
     }
     const int g = w >> 2, n = g*h, dx = mvx(mv) & 7, dy = mvy(mv) & 7;
     const int ix = cx + (mvx(mv) >> 3), iy = cy + (mvy(mv) >> 3);

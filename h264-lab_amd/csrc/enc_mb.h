@@ -32,6 +32,7 @@ struct RowLds
     BitW bw;
     int skip_run, lead_skips, coded_any;
     int far_reads;                                  /* reference accesses of this row that left the valid window */
+    int16_t slice_row[H264E_MAX_SLICES + 2];       /* this frame's slice start rows (copy of the task's) */
     int far_fail;                                   /* a dynamic wait behind such an access gave up (enc_kernels.h rv_wait_rect): -1 expired, -2 producer aborted */
     unsigned long long prof[32], prof_last, prof_c0, prof_w0;
 
@@ -240,7 +241,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
                         }, s4);
                     } else
                     {
-                        rv_wait_rect(R, cx + w, cy + h);
+                        rv_wait_rect(R, cy - 1, cx + w, cy + h);
                         wave_sum4([&](int l, int *sv) {
                             if (l >= n) return;
                             const int r = l >> (g >> 1), c4 = l & (g - 1);
@@ -332,7 +333,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
         int s8[8];
         const int fx0 = px + (mvx(mv) >> 2), fy0 = py + (mvy(mv) >> 2);
         const bool inside = rv_inside(R, fx0 - 5, fy0 - 3, fx0 + w + 4, fy0 + h + 3);      /* every probe is within one sample of mv */
-        if (!inside) rv_wait_rect(R, fx0 + w + 4, fy0 + h + 3);
+        if (!inside) rv_wait_rect(R, fy0 - 3, fx0 + w + 4, fy0 + h + 3);
         /* the 2x2 integer cell that holds the three half-sample positions: vdg = (+-1, +-1) says on which side of (x,y) it lies */
         const int hp_ox = mvx(vdg) < 0 ? 1 : 0, hp_oy = mvy(vdg) < 0 ? 1 : 0, hp_pq_vertical = mvx(pq) == 0;
         wave_sum8([&](int l, int *sv) {

@@ -57,6 +57,7 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
     L.bw.cap = (uint32_t)G.row_words;
     L.bw.buf = C.rowbits + (size_t)row*G.row_words;
     L.skip_run = 0; L.lead_skips = 0; L.coded_any = 0; L.far_reads = 0; L.far_fail = 0;
+    WAVE_FOR(l) { if (l <= H264E_MAX_SLICES) L.slice_row[l] = l <= T.nslices ? T.slice_row[l] : (int16_t)0x7fff; }
     WAVE_FOR(l)
     {
         for (int k = l; k < 84; k += 64) L.qdat[k/42][k%42] = T.qdat[k/42][k%42];
@@ -183,7 +184,7 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
     /* the input macroblock and the reference window are already in LDS (row_prefetch) */
     m.rv.dep = (const GLOBAL_AS int *)T.dep_progress; m.rv.nmbx = G.nmbx; m.rv.nmby = G.nmby;
     m.rv.P = m.ref[0]; m.rv.win = (const lu8 *)L.win; m.rv.has_win = T.slice_type == 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
-    m.rv.vw = NARROW ? H264E_NARROW_VW : WIN_W; m.rv.vh = NARROW ? H264E_NARROW_VH : WIN_W; m.rv.far = &L.far_reads; m.rv.fail = &L.far_fail;
+    m.rv.vw = NARROW ? H264E_NARROW_VW : WIN_W; m.rv.vh = NARROW ? H264E_NARROW_VH : WIN_W; m.rv.far = &L.far_reads; m.rv.fail = &L.far_fail; m.rv.slice_row = L.slice_row; m.rv.nslices = T.nslices;
     STAMP(L, 1);
 
     BitW bw = L.bw;

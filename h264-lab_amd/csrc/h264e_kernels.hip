@@ -123,7 +123,22 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
         if (row >= T.slice_row[k] && row < T.slice_row[k + 1]) { row0 = T.slice_row[k]; row1 = T.slice_row[k + 1]; }
     row0 = uni(row0); row1 = uni(row1);
     constexpr int DEP_ROWS = NARROW ? H264E_NARROW_DEP_ROWS : H264E_DEP_ROWS, DEP_COLS = NARROW ? H264E_NARROW_DEP_COLS : H264E_DEP_COLS;
-    const int dep_row = imin(row + DEP_ROWS, G.nmby - 1);
+    /* temporal wavefront: the reference window covers macroblock rows row-2 .. row+DEP_ROWS of the frame being referenced.
+     * Inside one slice the lowest of them is the last to get there; with row-band slices the bands advance independently, so
+     * every band the window touches is waited for at its lowest row inside the window (10 bits per row, lowest row first) */
+    unsigned long long deps = 0;
+    int ndeps = 0;
+    if (T.dep_progress)
+    {
+        const int lo = imax(row - 2, 0), hi = imin(row + DEP_ROWS, G.nmby - 1);
+        deps = (unsigned long long)hi; ndeps = 1;
+        for (int k = T.nslices - 1; k >= 1; k--)
+        {
+            const int last = T.slice_row[k] - 1;            /* last row of slice k-1 */
+            if (last >= lo && last < hi) { deps |= (unsigned long long)last << (10*ndeps); ndeps++; }
+        }
+        ndeps = uni(ndeps);
+    }
     for (int x = 0; x < G.nmbx; x++)
     {
         /* consumer: relaxed sc1 polls, then sc1 loads of everything handed over */
@@ -135,7 +150,14 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
         /* temporal dependency first, then the loads that only need it (input, reference window) ... */
         if (!st && seen_dep < need_dep)
         {
-            st = poll_progress((const GLOBAL_AS int *)T.dep_progress + dep_row, need_dep, seen_dep);
+            int lowest = 0x7fffffff;
+            for (int k = 0; k < ndeps && !st; k++)
+            {
+                int sk = 0;
+                st = poll_progress((const GLOBAL_AS int *)T.dep_progress + (int)((deps >> (10*k)) & 1023), need_dep, sk);
+                lowest = imin(lowest, sk);
+            }
+            seen_dep = lowest;
             if (!st) consumer_acquire();
         }
         if (!st) row_prefetch(L, G, T, row, x);
