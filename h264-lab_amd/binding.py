@@ -41,13 +41,13 @@ class IoYuv(C.Structure):  # h264-lab.h:231-237: 40 bytes
 
 class ClipParam(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("width", "height", "gop", "qp", "speed", "vbv_size_bytes", "device", "max_chains",
-                                       "first_idr_pic_id_state")] + [("mv_clusters_in", C.c_int32 * 2), ("slices", C.c_int), ("kbps", C.c_int)]
+                                       "first_idr_pic_id_state")] + [("mv_clusters_in", C.c_int32 * 2), ("slices", C.c_int), ("kbps", C.c_int), ("resident_frames", C.c_int)]
 
 
 class ClipStats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("upload_ms", "encode_ms", "readback_ms", "assemble_ms", "mb_kernel_ms", "splice_kernel_ms")] + \
                [(n, C.c_int) for n in ("kernel_launches", "chains", "rounds", "reencoded_gops")] + \
-               [("mv_clusters_out", C.c_int32 * 2), ("next_idr_pic_id_state", C.c_int)]
+               [("mv_clusters_out", C.c_int32 * 2), ("next_idr_pic_id_state", C.c_int), ("first_frame", C.c_int), ("frames", C.c_int)]
 
 
 def lib_path():
@@ -84,6 +84,11 @@ def load(path=None):
     L.H264E_clip_upload.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.H264E_clip_generate_synth.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32]
     L.H264E_clip_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.c_int, C.POINTER(ClipStats)]
+    L.H264E_clip_rewind.argtypes = [C.c_void_p]
+    L.H264E_clip_rewind.restype = None
+    L.H264E_clip_read_recon.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.H264E_clip_set_ssd_output.argtypes = [C.c_void_p, C.c_void_p]
+    L.H264E_clip_set_ssd_output.restype = None
     L.H264E_clip_close.argtypes = [C.c_void_p]
     L.H264E_clip_close.restype = None
     L.h264e_hip_device_count.restype = C.c_int
@@ -151,10 +156,10 @@ class ClipEncoder:
     """Whole-clip streaming encode on one GPU (H264E_clip_* extension): consecutive frames as a temporal wavefront."""
 
     def __init__(self, width, height, nframes, gop=30, qp=26, speed=0, device=0, max_chains=0, lib=None,
-                 clusters_in=(0, 0), idr_state=0, slices=0, kbps=0):
+                 clusters_in=(0, 0), idr_state=0, slices=0, kbps=0, resident=0):
         self.L = load(lib)
         self.w, self.h, self.n = width, height, nframes
-        self.par = ClipParam(width, height, gop, qp, speed, 100000 // 8, device, max_chains, idr_state, (C.c_int32 * 2)(*clusters_in), slices, kbps)
+        self.par = ClipParam(width, height, gop, qp, speed, 100000 // 8, device, max_chains, idr_state, (C.c_int32 * 2)(*clusters_in), slices, kbps, resident)
         self.c = C.c_void_p()
         if self.L.H264E_clip_open(C.byref(self.c), C.byref(self.par), nframes):
             raise _err(self.L, "H264E_clip_open")
@@ -169,15 +174,25 @@ class ClipEncoder:
         if self.L.H264E_clip_generate_synth(self.c, first, self.n if nframes is None else nframes, t0, seed):
             raise _err(self.L, "H264E_clip_generate_synth")
 
-    def encode(self, profile=False):
-        cap = self.w * self.h * 3 // 2 * self.n + (1 << 20)
+    def encode(self, profile=False, rewind=True, cap=None):
+        """Encode the uploaded frames that are not encoded yet (after a rewind: all of them).  Returns (bytes, sizes, stats)."""
+        if rewind:
+            self.L.H264E_clip_rewind(self.c)
+        cap = cap or (self.w * self.h * 3 // 2 * self.n + (1 << 20))
         out = np.empty(cap, np.uint8)
         nb = C.c_size_t()
         sizes = (C.c_int * self.n)()
         st = ClipStats()
         if self.L.H264E_clip_encode(self.c, out.ctypes.data, cap, C.byref(nb), sizes, int(profile), C.byref(st)):
             raise _err(self.L, "H264E_clip_encode")
-        return out[: nb.value].tobytes(), list(sizes), st
+        return out[: nb.value].tobytes(), list(sizes)[: st.frames], st
+
+    def read_recon(self, frame):
+        cw, ch = (self.w + 15) // 16 * 16, (self.h + 15) // 16 * 16
+        buf = np.empty(cw * ch * 3 // 2, np.uint8)
+        if self.L.H264E_clip_read_recon(self.c, frame, buf.ctypes.data):
+            raise _err(self.L, "H264E_clip_read_recon")
+        return buf
 
     def close(self):
         if self.c:

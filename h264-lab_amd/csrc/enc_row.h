@@ -547,17 +547,100 @@ DEV void finalize_frame(const h264e_geom_t &G, const ChainG &C, const h264e_fram
     wave_sync();
 }
 
-/* copy the finished frame's RBSP and macroblock records into host-mapped memory (16 bytes per lane per pass) */
-DEV void export_frame(const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T)
+/*
+ * RBSP -> Annex-B NAL on the device: 4-byte start code + payload with emulation prevention (h264-lab.h:3926-4022 nal_count_esc /
+ * nal_put_esc: a 0x03 goes in front of every byte <= 3 that follows two zero bytes; the zero count restarts behind it).
+ * The escape automaton is sequential, but it can only fire where the RAW bytes read 00 00 0x -- once per ~4 MB of CAVLC data.
+ * So: 256-byte blocks, one dword per lane; a ballot finds the blocks that contain such a triple (two bytes of look-back across
+ * the block edge); all other blocks are copied by the whole wave (shifted by the escapes inserted so far), a block with a
+ * candidate is run through the automaton byte by byte by one lane with the exact carried zero count.
+ * dst: 16-byte aligned (host-mapped memory or HBM).  Returns the NAL size; sets overflow when it does not fit cap.
+ */
+DEV uint32_t nal_escape_copy(GLOBAL_AS uint8_t *dst, uint32_t cap, const GLOBAL_AS uint8_t *src, uint32_t n, int &overflow)
+{
+    uint32_t esc = 0;           /* escapes inserted so far (wave-uniform) */
+    int cntz = 0;               /* the automaton's zero count in front of the current block (exact whenever it matters) */
+    if (n + 4u > cap) { overflow = 1; return 0; }
+    if (wave_lane() == 0) gstore32((gu8 *)dst, 0x01000000u);                /* 00 00 00 01 */
+    for (uint32_t base = 0; base < n; base += 256)
+    {
+        const uint32_t len = n - base < 256u ? n - base : 256u;
+        const uint64_t cand = wave_ballot([&](int l) -> int {
+            const uint32_t o = base + 4u*(uint32_t)l;
+            if (o >= n) return 0;
+            /* six raw bytes: two of look-back (0xff in front of the payload) and this lane's dword (the arena is zero-padded to a
+             * dword behind the payload: at worst a false candidate, which only selects the byte-wise path for this block) */
+            const uint32_t cur = gload32((const gu8 *)(src + o)), prev = o ? gload32((const gu8 *)(src + o - 4)) : 0xffffffffu;
+            const uint64_t w = ((uint64_t)cur << 16) | (uint64_t)(prev >> 16);
+            int hit = 0;
+            for (int k = 0; k < 4; k++)
+                if (((w >> (8*k)) & 0xffffu) == 0 && ((w >> (8*(k + 2))) & 0xffu) <= 3u) hit = 1;
+            return hit;
+        });
+        if (!cand)
+        {
+            /* no escape can fire inside this block: whole-wave copy, shifted by the escapes so far */
+            if (4u + base + esc + len > cap) { overflow = 1; return 0; }
+            WAVE_FOR(l)
+            {
+                const uint32_t o = 4u*(uint32_t)l;
+                if (o < len)
+                {
+                    GLOBAL_AS uint8_t *d = dst + 4u + base + esc + o;
+                    if (o + 4u <= len) gstore32((gu8 *)d, gload32((const gu8 *)(src + base + o)));
+                    else for (uint32_t k = o; k < len; k++) dst[4u + base + esc + k] = src[base + k];
+                }
+            }
+            /* zero count behind a block without escapes = its trailing raw zeros (at most 2, else it had a candidate) */
+            {
+                const uint32_t e = base + len;
+                cntz = src[e - 1] ? 0 : (e >= 2 && src[e - 2] == 0) ? 2 : 1;
+            }
+        } else
+        {
+            if (4u + base + esc + len + len/2 + 2u > cap) { overflow = 1; return 0; }
+            if (wave_lane() == 0)
+            {
+                uint32_t j = 4u + base + esc;
+                for (uint32_t i = 0; i < len; i++)
+                {
+                    const uint8_t b = src[base + i];
+                    if (cntz == 2 && b <= 3) { dst[j++] = 3; cntz = 0; esc++; }
+                    cntz = b ? 0 : cntz + 1;
+                    dst[j++] = b;
+                }
+            }
+#ifndef H264E_EMU
+            esc = (uint32_t)__builtin_amdgcn_readfirstlane((int)esc);       /* lane 0 ran the automaton: its counters are the wave's */
+            cntz = __builtin_amdgcn_readfirstlane(cntz);
+#endif
+        }
+        wave_sync();
+    }
+    return 4u + n + esc;
+}
+
+/* finished frame -> host-mapped memory: every slice as a complete Annex-B NAL (start code + escaped payload), the NALs behind
+ * each other at 16-byte aligned offsets, and the macroblock records (16 bytes per lane per pass).  Returns the NAL sizes. */
+DEV void export_frame(const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, uint32_t *nal_bytes /* [H264E_MAX_SLICES], uniform */, uint32_t &total, int &overflow)
 {
     const GLOBAL_AS h264e_frameout_t &F = C.fout[T.frame_slot];
-    const uint32_t nb = imin((int)F.nbytes, (int)T.host_rbsp_cap), nw = (nb + 15u) >> 4;
-    const GLOBAL_AS u32x4 *src = (const GLOBAL_AS u32x4 *)(C.arena + F.offset);
-    GLOBAL_AS u32x4 *dst = (GLOBAL_AS u32x4 *)T.host_rbsp;
-    for (uint32_t base = 0; base < nw; base += 64)
+    uint32_t soff = 0, doff = 0;
+    overflow = 0;
+    for (int k = 0; k < H264E_MAX_SLICES; k++)
     {
-        WAVE_FOR(l) { if (base + (uint32_t)l < nw) dst[base + l] = src[base + l]; }
+        nal_bytes[k] = 0;
+        if (k < F.nslices)
+        {
+            const uint32_t n = F.slice_nbytes[k];
+            const uint32_t room = doff < T.host_rbsp_cap ? T.host_rbsp_cap - doff : 0u;
+            const uint32_t w = nal_escape_copy((GLOBAL_AS uint8_t *)T.host_rbsp + doff, room, C.arena + F.offset + soff, n, overflow);
+            nal_bytes[k] = w;
+            soff += (n + 15u) & ~15u;
+            doff += (w + 15u) & ~15u;
+        }
     }
+    total = doff;
     const uint32_t nr = ((uint32_t)G.nmb*(uint32_t)sizeof(h264e_mbrec_t) + 15u) >> 4;
     const GLOBAL_AS u32x4 *rs = (const GLOBAL_AS u32x4 *)(C.mbrec + (size_t)T.frame_slot*G.nmb);
     GLOBAL_AS u32x4 *rd = (GLOBAL_AS u32x4 *)T.host_mbrec;

@@ -14,9 +14,11 @@
  * (no host threads are involved here: the slices are wavefronts of the same kernel launch).
  * Not kept: --gen (libm-dependent synthetic input), --denoise.
  *
- * Extras (new option names, also argv-consuming): --device N; --clip 1 encodes the whole file through the
- * GOP-parallel clip encoder (H264E_clip_*; same bitstream, constant QP only); --chains N bounds chains in flight.
+ * Extras (new option names, also argv-consuming): --device N; --clip 1 streams the file through the clip encoder (H264E_clip_*:
+ * consecutive frames as a temporal wavefront on the GPU, same bitstream, bounded host memory whatever the file size; --kbps,
+ * --threads, --psnr, --stats work there too); --chains N bounds the frames in flight per launch.
  */
+#define _FILE_OFFSET_BITS 64
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -151,40 +153,179 @@ static void psnr_print(void)                                                    
     printf("  \n");
 }
 
+/*
+ * --clip 1: the file streams through the clip encoder in bounded memory (minih264e_test.c:584 / :654 read one frame, encode it,
+ * write it -- here the same loop is a pipeline):
+ *   reader thread : fread() into one of two pinned staging buffers (H264E_clip_host_alloc)
+ *   copy engine   : staging buffer -> ring of input frames in HBM (H264E_clip_upload_async), issued and completed from the
+ *                   encoder's idle hook, i.e. while earlier frames are being encoded
+ *   GPU + caller  : H264E_clip_encode over the frames that have landed; its output buffer is flushed to the file when full
+ * --psnr does not bring reconstructions back to the host: the sums of squared differences are taken on the device.
+ */
+#include <pthread.h>
+#include <unistd.h>
+
+typedef struct
+{
+    FILE *fin;
+    size_t fsz;
+    int nframes, chunk;                 /* frames in the file region, frames per staging buffer */
+    uint8_t *buf[2];
+    int have[2];                        /* frames waiting in buf[k] (0 = free) */
+    int first[2];                       /* their first frame index */
+    int eof, error;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+} feeder_t;
+
+static void *feeder_thread(void *arg)
+{
+    feeder_t *f = (feeder_t *)arg;
+    int next = 0, k = 0;
+    while (next < f->nframes)
+    {
+        const int n = f->nframes - next < f->chunk ? f->nframes - next : f->chunk;
+        pthread_mutex_lock(&f->mu);
+        while (f->have[k]) pthread_cond_wait(&f->cv, &f->mu);
+        pthread_mutex_unlock(&f->mu);
+        if (fread(f->buf[k], f->fsz, (size_t)n, f->fin) != (size_t)n) { f->error = 1; break; }
+        pthread_mutex_lock(&f->mu);
+        f->first[k] = next; f->have[k] = n;
+        pthread_cond_broadcast(&f->cv);
+        pthread_mutex_unlock(&f->mu);
+        next += n; k ^= 1;
+    }
+    pthread_mutex_lock(&f->mu);
+    f->eof = 1;
+    pthread_cond_broadcast(&f->cv);
+    pthread_mutex_unlock(&f->mu);
+    return NULL;
+}
+
+typedef struct { feeder_t *f; H264E_clip_t *clip; int resident, inflight /* buffer being copied, or -1 */, next_buf; } pump_t;
+
+/* idle hook: finish the copy in flight, start the next one if a buffer is ready and the input ring has room */
+static void pump(void *token)
+{
+    pump_t *p = (pump_t *)token;
+    feeder_t *f = p->f;
+    if (p->inflight >= 0 && H264E_clip_upload_poll(p->clip) == 1)
+    {
+        pthread_mutex_lock(&f->mu);
+        f->have[p->inflight] = 0;
+        pthread_cond_broadcast(&f->cv);
+        pthread_mutex_unlock(&f->mu);
+        p->inflight = -1;
+    }
+    if (p->inflight < 0)
+    {
+        int n, first, next_frame;
+        pthread_mutex_lock(&f->mu);
+        n = f->have[p->next_buf]; first = f->first[p->next_buf];
+        pthread_mutex_unlock(&f->mu);
+        H264E_clip_position(p->clip, &next_frame, NULL);
+        if (n && first + n - p->resident <= next_frame && !H264E_clip_upload_async(p->clip, first, n, f->buf[p->next_buf]))
+        {
+            p->inflight = p->next_buf;
+            p->next_buf ^= 1;
+        }
+    }
+}
+
 static int run_clip_mode(FILE *fin, FILE *fout, int w, int h)
 {
     const size_t fsz = (size_t)w*h*3/2;
+    /* budgets (host: two staging buffers + the output buffer; HBM: the input ring); the environment overrides exist for tests that
+     * want the ring to wrap and the output buffer to fill on tiny clips */
+    const size_t stage_bytes = getenv("H264E_APP_STAGE_KB") ? (size_t)atol(getenv("H264E_APP_STAGE_KB")) << 10 : (size_t)384 << 20;
+    const size_t ring_bytes = getenv("H264E_APP_RING_KB") ? (size_t)atol(getenv("H264E_APP_RING_KB")) << 10 : (size_t)6 << 30;
+    const size_t out_cap = getenv("H264E_APP_OUT_KB") ? (size_t)atol(getenv("H264E_APP_OUT_KB")) << 10 : (size_t)64 << 20;
     H264E_clip_param_t par;
     H264E_clip_stats_t st;
     H264E_clip_t *clip = NULL;
-    long total;
-    int n, i, *sizes;
-    uint8_t *buf, *out;
-    size_t nb = 0;
-    fseek(fin, 0, SEEK_END);
-    total = ftell(fin);
-    fseek(fin, 0, SEEK_SET);
-    n = (int)((size_t)total/fsz);
+    feeder_t fd;
+    pump_t pp;
+    pthread_t th;
+    long long total;
+    int n, i, *sizes, done = 0, rc = 1, rounds = 0, relaunches = 0;
+    uint8_t *out;
+    uint64_t *ssd = NULL;
+    double enc_ms = 0;
+    fseeko(fin, 0, SEEK_END);
+    total = (long long)ftello(fin);
+    fseeko(fin, 0, SEEK_SET);
+    n = (int)((unsigned long long)total/fsz);
     if (n <= 0) return 0;
     memset(&par, 0, sizeof(par));
     par.width = w; par.height = h; par.gop = cmd.gop; par.qp = cmd.qp; par.speed = cmd.speed; par.vbv_size_bytes = 100000/8;
-    par.device = cmd.device < 0 ? 0 : cmd.device; par.max_chains = cmd.chains; par.slices = cmd.threads;
-    buf = (uint8_t *)malloc(fsz*(size_t)n);
-    out = (uint8_t *)malloc(fsz*(size_t)n + (1 << 20));
+    par.device = cmd.device < 0 ? 0 : cmd.device; par.max_chains = cmd.chains; par.slices = cmd.threads; par.kbps = cmd.kbps;
+    memset(&fd, 0, sizeof(fd));
+    fd.fin = fin; fd.fsz = fsz; fd.nframes = n;
+    fd.chunk = (int)(stage_bytes/fsz); if (fd.chunk < 1) fd.chunk = 1; if (fd.chunk > n) fd.chunk = n;
+    par.resident_frames = (int)(ring_bytes/fsz);
+    if (par.resident_frames < 4*fd.chunk) par.resident_frames = 4*fd.chunk;
+    if (par.resident_frames > n) par.resident_frames = n;
+    pthread_mutex_init(&fd.mu, NULL); pthread_cond_init(&fd.cv, NULL);
+    fd.buf[0] = (uint8_t *)H264E_clip_host_alloc(fsz*(size_t)fd.chunk);
+    fd.buf[1] = (uint8_t *)H264E_clip_host_alloc(fsz*(size_t)fd.chunk);
+    out = (uint8_t *)malloc(out_cap > 2*fsz + (1 << 16) ? out_cap : 2*fsz + (1 << 16));
     sizes = (int *)malloc(sizeof(int)*(size_t)n);
-    if (!buf || !out || !sizes || fread(buf, fsz, (size_t)n, fin) != (size_t)n) { printf("ERROR: not enough memory / short read\n"); return 1; }
-    if (H264E_clip_open(&clip, &par, n) || H264E_clip_upload(clip, 0, n, buf) ||
-        H264E_clip_encode(clip, out, fsz*(size_t)n + (1 << 20), &nb, sizes, 0, &st))
+    if (cmd.psnr) ssd = (uint64_t *)malloc(sizeof(uint64_t)*3*(size_t)n);
+    if (!fd.buf[0] || !fd.buf[1] || !out || !sizes || (cmd.psnr && !ssd)) { printf("ERROR: not enough memory\n"); return 1; }
+    if (H264E_clip_open(&clip, &par, n)) { printf("ERROR: %s\n", H264E_last_error()); return 1; }
+    pp.f = &fd; pp.clip = clip; pp.resident = par.resident_frames; pp.inflight = -1; pp.next_buf = 0;
+    H264E_clip_set_idle_hook(clip, pump, &pp);
+    if (pthread_create(&th, NULL, feeder_thread, &fd)) { printf("ERROR: cannot start the reader thread\n"); return 1; }
+    while (done < n)
     {
-        printf("ERROR: %s\n", H264E_last_error());
-        return 1;
+        int next_frame, avail;
+        size_t nb = 0;
+        pump(&pp);
+        H264E_clip_position(clip, &next_frame, &avail);
+        if (avail <= next_frame)
+        {
+            if (fd.error) { printf("ERROR: short read\n"); goto out; }
+            usleep(200);
+            continue;
+        }
+        if (ssd) H264E_clip_set_ssd_output(clip, ssd);
+        if (H264E_clip_encode(clip, out, out_cap > 2*fsz + (1 << 16) ? out_cap : 2*fsz + (1 << 16), &nb, sizes, 0, &st)) { printf("ERROR: %s\n", H264E_last_error()); goto out; }
+        if (nb && !fwrite(out, nb, 1, fout)) { printf("ERROR writing output file\n"); goto out; }
+        for (i = 0; i < st.frames; i++)
+        {
+            if (cmd.stats) printf("frame=%d, bytes=%d\n", st.first_frame + i, sizes[i]);
+            if (ssd)
+            {
+                int k, pw = w, ph = h;
+                for (k = 0; k < 3; k++)
+                {
+                    g_psnr.count[k] += pw*ph;
+                    g_psnr.noise[k] += (double)ssd[3*i + k];
+                    if (!k) pw >>= 1, ph >>= 1;
+                }
+                g_psnr.frames++;
+                g_psnr.bytes += sizes[i];
+            }
+        }
+        done += st.frames; rounds += st.rounds; relaunches += st.reencoded_gops; enc_ms += st.encode_ms;
     }
-    if (cmd.stats) for (i = 0; i < n; i++) printf("frame=%d, bytes=%d\n", i, sizes[i]);
-    if (!fwrite(out, nb, 1, fout)) printf("ERROR writing output file\n");
-    fprintf(stderr, "clip: %d frames, %d chains, %d rounds, %d re-encoded GOPs, encode %.1f ms\n", n, st.chains, st.rounds, st.reencoded_gops, st.encode_ms);
+    rc = 0;
+    if (cmd.psnr) psnr_print();
+    fprintf(stderr, "clip: %d frames, %d in flight per launch, %d launches (%d after a mis-speculated mv_clusters state), encode %.1f ms, input ring %d frames, staging 2 x %d frames\n",
+            n, st.chains, rounds, relaunches, enc_ms, par.resident_frames, fd.chunk);
+out:
+    /* let the reader finish (it may be blocked on a full buffer) */
+    pthread_mutex_lock(&fd.mu);
+    fd.nframes = 0; fd.have[0] = fd.have[1] = 0;
+    pthread_cond_broadcast(&fd.cv);
+    pthread_mutex_unlock(&fd.mu);
+    if (rc) pthread_cancel(th);
+    pthread_join(th, NULL);
+    (void)H264E_clip_upload_wait(clip);
     H264E_clip_close(clip);
-    free(buf); free(out); free(sizes);
-    return 0;
+    H264E_clip_host_free(fd.buf[0]); H264E_clip_host_free(fd.buf[1]);
+    free(out); free(sizes); free(ssd);
+    return rc;
 }
 
 int main(int argc, char **argv)
@@ -220,7 +361,7 @@ int main(int argc, char **argv)
     if (error) { printf("H264E_init error = %d\n", error); return 0; }
     printf("sizeof_persist = %d sizeof_scratch = %d\n", sizeof_persist, sizeof_scratch);
 
-    if (cmd.clip && !cmd.kbps && !cmd.psnr)
+    if (cmd.clip)
     {
         int r = run_clip_mode(fin, fout, w, h);
         fclose(fin); fclose(fout);

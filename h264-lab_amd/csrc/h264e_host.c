@@ -155,18 +155,6 @@ static size_t nal_emit(uint8_t *d, const uint8_t *p, size_t n)
     return j;
 }
 
-static size_t nal_escaped_size(const uint8_t *p, size_t n)
-{
-    size_t i, extra = 0;
-    int zeros = 0;
-    for (i = 0; i < n; i++)
-    {
-        if (zeros == 2 && p[i] <= 3) { extra++; zeros = 0; }
-        zeros = p[i] ? 0 : zeros + 1;
-    }
-    return 4 + n + extra;
-}
-
 typedef struct
 {
     int width, height, nmbx, nmby, nmb, w, h, cropping;
@@ -262,18 +250,21 @@ static void slice_header_bits(const seq_t *s, int key, int frame_num, int idr_pi
     *nbits = b.n;
 }
 
-/* the slices of one frame as the kernel exports them (h264e_hip_result_t): start code + escaped payload for each, in order
- * (h264-lab.h:6565-6569 concatenates the band outputs); cb as in nal_end.  Returns bytes written, 0 when cap is too small */
-static size_t emit_slices(uint8_t *d, size_t cap, const uint8_t *rb, const h264e_hip_result_t *r, nalu_cb_t cb, void *token)
+/* the slices of one frame as the kernel exports them (h264e_hip_result_t): complete NALs -- start code + payload with the
+ * emulation-prevention bytes already inserted on the device (enc_row.h nal_escape_copy) -- behind each other at 16-byte
+ * aligned offsets; they are concatenated in order (h264-lab.h:6565-6569), cb as in nal_end.  Returns bytes written, 0 when
+ * cap is too small */
+static size_t emit_slices(uint8_t *d, size_t cap, const uint8_t *nals, const h264e_hip_result_t *r, nalu_cb_t cb, void *token)
 {
     size_t pos = 0, off = 0;
     int k;
     for (k = 0; k < r->nslices; k++)
     {
-        const size_t n = r->slice_nbytes[k], need = nal_escaped_size(rb + off, n);
-        if (pos + need > cap) return 0;
-        pos += nal_emit(d + pos, rb + off, n);
-        if (cb) cb(d + pos - (need - 4), (int)(need - 4), token);
+        const size_t n = r->slice_nbytes[k];
+        if (n < 5 || pos + n > cap) return 0;
+        memcpy(d + pos, nals + off, n);
+        if (cb) cb(d + pos + 4, (int)(n - 4), token);
+        pos += n;
         off += (n + 15) & ~(size_t)15;
     }
     return pos;
@@ -447,23 +438,28 @@ static int step_exact(h264e_hip_pool_t *pool, int nchains, h264e_hip_task_t *tas
     for (pass = 0; pending; pass++)
     {
         if (pass > nmb + 2) { snprintf(g_host_err, sizeof(g_host_err), "mv_clusters re-encode does not converge"); goto done; }
-        if (h264e_hip_submit(pool, tasks) || h264e_hip_sync(pool) || h264e_hip_step_flags(pool, flags)) goto done;
+        if (h264e_hip_submit(pool, tasks) || h264e_hip_sync(pool)) goto done;
         for (k = 0; k < nchains; k++)
         {
             int32_t cc[2];
             int bad;
+            h264e_hip_result_t r1;
+            const h264e_hip_mbrec_t *recs;
             if (!todo[k]) continue;
+            /* results come through host-mapped memory, written by the frame's finalizer workgroup (no device-to-host copies) */
+            if (h264e_hip_stream_done(pool, k, &r1) != 1) { snprintf(g_host_err, sizeof(g_host_err), "frame did not complete"); goto done; }
+            flags[2*k] = r1.clusters_moved; flags[2*k + 1] = r1.overflow;
             if (flags[2*k + 1]) { snprintf(g_host_err, sizeof(g_host_err), "bit buffer overflow"); goto done; }
             if (!arr[k] && !flags[2*k]) { todo[k] = 0; tasks[k].active = 0; pending--; continue; }   /* fixed point: state unchanged */
-            if (!rec)
+            if (!traj)
             {
-                rec = (h264e_hip_mbrec_t *)malloc(sizeof(*rec)*(size_t)nmb);
                 traj = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb);
-                if (!rec || !traj) goto done;
+                if (!traj) goto done;
             }
-            if (h264e_hip_read_mbrec(pool, k, tasks[k].frame_slot, rec)) goto done;
+            recs = h264e_hip_stream_mbrec(pool, k);
+            if (!recs) goto done;
             cc[0] = run[k][0]; cc[1] = run[k][1];
-            bad = clusters_walk(cc, rec, nmbx, nmby, tasks[k].nslices, arr[k] ? arr[k] : run[k], arr[k] != NULL, traj) >= 0;
+            bad = clusters_walk(cc, recs, nmbx, nmby, tasks[k].nslices, arr[k] ? arr[k] : run[k], arr[k] != NULL, traj) >= 0;
             if (!bad)
             {
                 run[k][0] = cc[0]; run[k][1] = cc[1];
@@ -694,7 +690,7 @@ int H264E_encode(H264E_persist_t *p, H264E_scratch_t *scratch, const H264E_run_p
     impl_t mm, *m = impl_of(e, &mm) ? &mm : NULL;
     uint8_t *out = (uint8_t *)scratch;
     size_t out_pos = 0, cap;
-    int frame_type, key, qp, sp, ss, n;
+    int frame_type, key, qp, sp, ss;
     h264e_hip_task_t task;
     h264e_hip_result_t res;
     const uint8_t *yuv[3];
@@ -741,14 +737,11 @@ int H264E_encode(H264E_persist_t *p, H264E_scratch_t *scratch, const H264E_run_p
     if (h264e_hip_reset_results(m->pool, 0) || h264e_hip_upload_planes(m->pool, 0, yuv, in->stride)) return H264E_STATUS_BAD_ARGUMENT;
     {
         int32_t run[1][2] = { { e->clusters[0], e->clusters[1] } };
-        if (step_exact(m->pool, 1, &task, e->seq.nmbx, e->seq.nmby, run, NULL, NULL) || h264e_hip_result(m->pool, 0, 0, &res)) return H264E_STATUS_BAD_ARGUMENT;
+        if (step_exact(m->pool, 1, &task, e->seq.nmbx, e->seq.nmby, run, NULL, NULL) || h264e_hip_stream_done(m->pool, 0, &res) != 1) return H264E_STATUS_BAD_ARGUMENT;
         e->clusters[0] = run[0][0]; e->clusters[1] = run[0][1];
     }
-    if (res.nbytes > m->rbsp_cap) return H264E_STATUS_BAD_ARGUMENT;
-    n = h264e_hip_read_rbsp(m->pool, 0, 0, m->rbsp, (uint32_t)m->rbsp_cap);
-    if (n < 0) return H264E_STATUS_BAD_ARGUMENT;
     {
-        const size_t w = (size_t)n == res.nbytes ? emit_slices(out + out_pos, cap - out_pos, m->rbsp, &res, opt->nalu_callback, opt->nalu_callback_token) : 0;
+        const size_t w = emit_slices(out + out_pos, cap - out_pos, h264e_hip_stream_rbsp(m->pool, 0), &res, opt->nalu_callback, opt->nalu_callback_token);
         if (!w)
         {
             snprintf(g_host_err, sizeof(g_host_err), "coded frame does not fit the scratch blob");
@@ -786,13 +779,34 @@ int H264E_encode(H264E_persist_t *p, H264E_scratch_t *scratch, const H264E_run_p
  * frames start immediately.  All frames of a launch speculate the mv_clusters state known when the launch starts;
  * afterwards the host validates them in order (exact walk of the per-macroblock records) and relaunches from the
  * first frame whose consumed candidates differ -- that frame with exact per-macroblock values.
+ *
+ * The encoder is resumable: H264E_clip_encode() encodes the frames that have been uploaded and not yet encoded (or as many
+ * as fit the caller's output buffer) and keeps every piece of stream state -- position, mv_clusters, idr parity, rate
+ * control, reference pictures -- for the next call.  Input frames live in a ring of `resident` HBM slots, so a file of any
+ * length streams through a bounded amount of host and device memory (encode_app --clip).
  */
 struct H264E_clip_tag
 {
     H264E_clip_param_t par;
     seq_t seq;
     int nframes, gop_len, ring;
+    int resident;                           /* input frames kept in HBM (ring): frame f lives in slot f % resident */
     h264e_hip_pool_t *pool;
+    /* ---- stream state, kept across H264E_clip_encode calls */
+    int next;                               /* next frame to encode */
+    int avail;                              /* frames [0, avail) have been uploaded / generated */
+    int pending_avail;                      /* ... once the asynchronous uploads in flight have landed */
+    void (*idle_hook)(void *token); void *idle_token;   /* called while the encoder waits for the GPU (the app feeds uploads from it) */
+    int32_t state[2];                       /* exact mv_clusters in front of frame `next` */
+    int32_t *first_arr;                     /* per-macroblock trajectory for a frame that is encoded again, or NULL */
+    int first_row;                          /* ... which restarts at this macroblock row */
+    int32_t after[2]; int have_after;       /* predicted state behind that frame */
+    int narrow;                             /* reference-window geometry in use (h264e_dev.h) */
+    rc_t rcs; int rc_frame, rc_qp;          /* rate control: state, the frame rc_frame_start has run for, its QP */
+    uint64_t *ssd_out;                      /* optional: [3] sums of squared differences input vs reconstruction per encoded frame of a call */
+    int32_t *traj;                          /* scratch: walked trajectory [nmb][2] */
+    h264e_hip_task_t *tasks;                /* scratch [ring] */
+    int32_t (*used)[2];                     /* scratch [ring] */
 };
 
 static double now_ms(void)
@@ -800,6 +814,21 @@ static double now_ms(void)
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec*1e3 + ts.tv_nsec*1e-6;
+}
+
+void H264E_clip_rewind(H264E_clip_t *c)
+{
+    if (!c) return;
+    c->next = 0;
+    c->state[0] = c->par.mv_clusters_in[0]; c->state[1] = c->par.mv_clusters_in[1];
+    free(c->first_arr); c->first_arr = NULL;
+    c->first_row = 0; c->have_after = 0;
+    /* reference-window geometry (h264e_dev.h): narrow = consecutive frames 4 macroblock steps apart, as long as vectors rarely
+     * reach more than 12 samples right / down of their macroblock; wide (7 steps) for the rest of the clip otherwise.  Large
+     * pictures already fill the GPU's resident workgroups with the wide geometry: the narrow one only pays below ~12k macroblocks */
+    c->narrow = (getenv("H264E_WIDE_WINDOW") || c->seq.nmb > 12000) ? 0 : 1;
+    memset(&c->rcs, 0, sizeof(c->rcs));
+    c->rc_frame = -1; c->rc_qp = c->par.qp;
 }
 
 int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nframes)
@@ -813,7 +842,7 @@ int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nfram
     c->par.qp = imin(imax(par->qp, 10), 51);
     seq_init(&c->seq, par->width, par->height, par->vbv_size_bytes, 0);
     c->nframes = nframes;
-    c->gop_len = par->gop ? par->gop : nframes;
+    c->gop_len = par->gop ? par->gop : (1 << 30);
     /* ring of picture / result slots = frames per launch + 1.  Not bounded by residency: workgroups only wait for lower
      * block indices, so a launch larger than the GPU simply streams through it in order. */
     /* default: 96 frames per launch at 1080p and above; small pictures have short pipelines and cheap slots, so they get
@@ -824,11 +853,16 @@ int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nfram
     }
     if (getenv("H264E_RING")) c->ring = atoi(getenv("H264E_RING"));       /* experiments */
     c->ring = imax(2, imin(c->ring, nframes + 1));
-    if (h264e_hip_pool_create(&c->pool, par->device, par->width, par->height, c->ring, nframes, 1))
+    c->resident = par->resident_frames > 0 ? imin(par->resident_frames, nframes) : nframes;
+    c->traj = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)c->seq.nmb);
+    c->tasks = (h264e_hip_task_t *)calloc((size_t)c->ring, sizeof(*c->tasks));
+    c->used = (int32_t (*)[2])calloc((size_t)c->ring, sizeof(int32_t[2]));
+    if (!c->traj || !c->tasks || !c->used || h264e_hip_pool_create(&c->pool, par->device, par->width, par->height, c->ring, c->resident, 1))
     {
-        free(c);
+        free(c->traj); free(c->tasks); free(c->used); free(c);
         return -1;
     }
+    H264E_clip_rewind(c);
     *out = c;
     return 0;
 }
@@ -837,22 +871,85 @@ void H264E_clip_close(H264E_clip_t *c)
 {
     if (!c) return;
     h264e_hip_pool_destroy(c->pool);
+    free(c->first_arr); free(c->traj); free(c->tasks); free(c->used);
     free(c);
+}
+
+/* frames [first, first + n) of the stream into their ring slots; a slot may only be overwritten once its old frame is encoded */
+static int clip_put(H264E_clip_t *c, int first, int n, const uint8_t *i420, int async)
+{
+    const size_t fsz = (size_t)c->seq.width*c->seq.height*3/2;
+    int done = 0;
+    if (!c || first < 0 || n < 0 || first + n > c->nframes) { snprintf(g_host_err, sizeof(g_host_err), "upload: bad frame range"); return -1; }
+    if (first + n - c->resident > c->next) { snprintf(g_host_err, sizeof(g_host_err), "upload: input ring full (frames %d.. are not encoded yet)", c->next); return -1; }
+    while (done < n)
+    {
+        const int slot = (first + done) % c->resident, run = imin(n - done, c->resident - slot);
+        if (async ? h264e_hip_upload_i420_async(c->pool, slot, run, i420 + fsz*(size_t)done) : h264e_hip_upload_i420(c->pool, slot, run, i420 + fsz*(size_t)done)) return -1;
+        done += run;
+    }
+    if (async) { if (first + n > c->pending_avail) c->pending_avail = first + n; }
+    else if (first + n > c->avail) c->avail = first + n;
+    return 0;
 }
 
 int H264E_clip_upload(H264E_clip_t *c, int first, int nframes, const uint8_t *i420)
 {
-    if (!c) return -1;
-    if (h264e_hip_upload_i420(c->pool, first, nframes, i420)) return -1;
+    if (clip_put(c, first, nframes, i420, 0)) return -1;
     return h264e_hip_sync(c->pool);
 }
 
-int H264E_clip_generate_synth(H264E_clip_t *c, int first, int nframes, int t0, uint32_t seed)
+/* the same from pinned host memory (H264E_clip_host_alloc) on the pool's copy stream: returns at once, the frames count as
+ * uploaded after H264E_clip_upload_wait() */
+int H264E_clip_upload_async(H264E_clip_t *c, int first, int nframes, const uint8_t *pinned_i420) { return clip_put(c, first, nframes, pinned_i420, 1); }
+int H264E_clip_upload_wait(H264E_clip_t *c)
+{
+    if (!c || h264e_hip_upload_wait(c->pool)) return -1;
+    if (c->pending_avail > c->avail) c->avail = c->pending_avail;
+    return 0;
+}
+/* 1 = every asynchronous upload has landed (the frames now count as uploaded), 0 = still copying */
+int H264E_clip_upload_poll(H264E_clip_t *c)
 {
     if (!c) return -1;
-    if (h264e_hip_generate_synth(c->pool, first, nframes, t0, seed)) return -1;
+    if (h264e_hip_upload_busy(c->pool)) return 0;
+    if (c->pending_avail > c->avail) c->avail = c->pending_avail;
+    return 1;
+}
+void H264E_clip_position(const H264E_clip_t *c, int *next_frame, int *uploaded_frames)
+{
+    if (next_frame) *next_frame = c ? c->next : 0;
+    if (uploaded_frames) *uploaded_frames = c ? c->avail : 0;
+}
+void H264E_clip_set_idle_hook(H264E_clip_t *c, void (*hook)(void *token), void *token) { if (c) { c->idle_hook = hook; c->idle_token = token; } }
+void *H264E_clip_host_alloc(size_t bytes) { return h264e_hip_host_alloc(bytes); }
+void H264E_clip_host_free(void *p) { h264e_hip_host_free(p); }
+
+int H264E_clip_generate_synth(H264E_clip_t *c, int first, int nframes, int t0, uint32_t seed)
+{
+    int done = 0;
+    if (!c || first < 0 || nframes < 0 || first + nframes > c->nframes || first + nframes - c->resident > c->next) return -1;
+    while (done < nframes)
+    {
+        const int slot = (first + done) % c->resident, run = imin(nframes - done, c->resident - slot);
+        if (h264e_hip_generate_synth(c->pool, slot, run, t0 + done, seed)) return -1;
+        done += run;
+    }
+    if (first + nframes > c->avail) c->avail = first + nframes;
     return h264e_hip_sync(c->pool);
 }
+
+/* reconstruction of an already encoded frame (coded size, packed I420), while its picture slot has not been reused: the last
+ * ring - 1 frames */
+int H264E_clip_read_recon(H264E_clip_t *c, int frame, uint8_t *dst)
+{
+    if (!c || !dst || frame < 0 || frame >= c->next || frame < c->next - (c->ring - 1)) return -1;
+    return h264e_hip_read_recon_slot(c->pool, frame % c->ring, dst);
+}
+
+/* [3] sums of squared differences (Y, U, V; input vs reconstruction) per frame encoded by the following H264E_clip_encode calls,
+ * computed on the device (encode_app --psnr); NULL switches it off */
+void H264E_clip_set_ssd_output(H264E_clip_t *c, uint64_t *ssd) { if (c) c->ssd_out = ssd; }
 
 /* diagnostic (stamps build): per-phase cycle sums since the last call */
 int H264E_clip_stamps(H264E_clip_t *c, unsigned long long *dst) { return c ? h264e_hip_stamps_read(c->pool, dst, 1) : -1; }
@@ -865,58 +962,46 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
      * a frame's QP is a function of the byte count of the frame before it (h264-lab.h:5924-6141) and moves almost every
      * frame, so frames cannot overlap: one frame per launch, the controller on the host between launches */
     const int rc_on = c->par.kbps > 0, desired_frame_bytes = c->par.kbps*1000/8/30, qp_min = rc_on ? 10 : c->par.qp, qp_max = rc_on ? 50 : c->par.qp;
-    int qp = c->par.qp, rc_frame = -1;      /* rc_frame: the frame rc_frame_start has already run for (a re-encode keeps its QP) */
-    rc_t rcs;
     const int pic_init_qp = imax(imin(30, qp_max), qp_min);     /* h264-lab.h:6768-6770 */
     const int idr_state = c->par.first_idr_pic_id_state & 1;
-    h264e_hip_task_t *tasks = (h264e_hip_task_t *)calloc((size_t)K, sizeof(*tasks));
-    int *flags = (int *)calloc(2*(size_t)K, sizeof(int));
-    int32_t (*used)[2] = (int32_t (*)[2])calloc((size_t)K, sizeof(int32_t[2]));
-    h264e_hip_mbrec_t *rec = (h264e_hip_mbrec_t *)malloc(sizeof(h264e_hip_mbrec_t)*(size_t)nmb);
-    int32_t *traj = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb), *first_arr = NULL;
-    const size_t rbsp_cap = (size_t)nmb*640 + 2048;
-    uint8_t *rbsp = (uint8_t *)malloc(rbsp_cap);      /* unused by the streaming path, kept for the size check */
-    int32_t state[2] = { c->par.mv_clusters_in[0], c->par.mv_clusters_in[1] };
-    int first_row = 0;                      /* the frame that is encoded again restarts at the first divergent macroblock row */
-    /* reference-window geometry (h264e_dev.h): narrow = consecutive frames 4 macroblock steps apart, as long as vectors
-     * rarely reach more than 12 samples right / down of their macroblock; wide (7 steps) for the rest of the clip otherwise */
-    /* large pictures already fill the GPU's resident workgroups with the wide geometry: the narrow one only pays below ~12k macroblocks */
-    int narrow = (getenv("H264E_WIDE_WINDOW") || nmb > 12000) ? 0 : 1;
+    const int first = c->next;
+    h264e_hip_task_t *tasks = c->tasks;
+    int32_t (*used)[2] = c->used;
     long long far_reads = 0;
-    int32_t after[2] = { 0, 0 };            /* after a failed validation: predicted state behind the frame that is encoded again */
-    int have_after = 0;
     uint16_t qdat_i[2][42], qdat_p[2][42];
     size_t pos = 0;
-    int rc = -1, n = 0, i;
+    int rc = -1, i, full = 0, qp = c->rc_qp;
     H264E_clip_stats_t stats;
     double t0;
     memset(&stats, 0, sizeof(stats));
     g_host_err[0] = 0;
-    if (!tasks || !flags || !used || !rec || !traj || !rbsp) goto done;
-    memset(&rcs, 0, sizeof(rcs));
     build_qdat(qdat_i, qp, 0);
     build_qdat(qdat_p, qp, 1);
     h264e_hip_profile(c->pool, profile);
     stats.chains = K - 1;
+    stats.first_frame = first;
 
-    while (n < c->nframes)
+    while (c->next < c->avail && !full)
     {
-        const int F = rc_on ? 1 : imin(K - 1, c->nframes - n);
+        const int n = c->next, limit = c->avail;       /* frames uploaded from the idle hook during this launch join the next one */
+        /* with --psnr style statistics every frame's picture must still be in its slot when the launch has drained */
+        const int F = rc_on ? 1 : imin(K - 1, limit - n);
         int nvalid = 0;
         t0 = now_ms();
         memset(tasks, 0, sizeof(*tasks)*(size_t)K);
-        if (rc_on && rc_frame != n)
+        if (rc_on && c->rc_frame != n)
         {
             const int key = (n % G) == 0;
-            qp = rc_frame_start(&rcs, c->par.gop, nmb, c->par.vbv_size_bytes, desired_frame_bytes, qp_min, qp_max, key);
+            qp = c->rc_qp = rc_frame_start(&c->rcs, c->par.gop, nmb, c->par.vbv_size_bytes, desired_frame_bytes, qp_min, qp_max, key);
             build_qdat(key ? qdat_i : qdat_p, qp, !key);
-            rc_frame = n;
-        }
+            c->rc_frame = n;
+        } else if (rc_on)
+            build_qdat((n % G) == 0 ? qdat_i : qdat_p, qp, (n % G) != 0);
         for (i = 0; i < F; i++)
         {
             h264e_hip_task_t *t = tasks + i;
             const int f = n + i, key = (f % G) == 0;
-            t->active = 1; t->frame_index = f; t->frame_slot = 0;
+            t->active = 1; t->frame_index = f % c->resident; t->frame_slot = 0;
             t->slice_type = key ? SLICE_I : SLICE_P;
             t->qp = qp; t->speed = c->par.speed;
             /* frame_num restarts at every key frame; idr_pic_id toggles with every key frame (h264-lab.h:6774-6775) */
@@ -927,14 +1012,14 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             t->ref_slot = key ? -1 : (f - 1) % K;
             t->ref_in_flight = !key && i > 0;
             /* frame 0 of the launch gets the exact state; the frames behind it the best prediction of what it leaves */
-            t->mv_clusters[0] = used[i][0] = (i && have_after) ? after[0] : state[0];
-            t->mv_clusters[1] = used[i][1] = (i && have_after) ? after[1] : state[1];
-            t->mv_clusters_per_mb = (i == 0) ? first_arr : NULL;
-            t->first_row = (i == 0 && first_arr) ? first_row : 0;
-            t->narrow_window = narrow;
+            t->mv_clusters[0] = used[i][0] = (i && c->have_after) ? c->after[0] : c->state[0];
+            t->mv_clusters[1] = used[i][1] = (i && c->have_after) ? c->after[1] : c->state[1];
+            t->mv_clusters_per_mb = (i == 0) ? c->first_arr : NULL;
+            t->first_row = (i == 0 && c->first_arr) ? c->first_row : 0;
+            t->narrow_window = c->narrow;
         }
         stats.rounds++;
-        have_after = 0;
+        c->have_after = 0;
         const double t_submit = now_ms();
         double t_first = 0, t_last = 0;
         if (h264e_hip_submit(c->pool, tasks)) goto done;
@@ -942,12 +1027,13 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
         /* consume the frames in stream order while the launch is still running */
         for (i = 0; i < F; i++)
         {
-            const int f = n + i, key = (f % G) == 0, slot = f % K, per_mb = (i == 0 && first_arr != NULL);
+            const int f = n + i, key = (f % G) == 0, slot = f % K, per_mb = (i == 0 && c->first_arr != NULL);
             h264e_hip_result_t r1;
             int dn, idle = 0;
             while ((dn = h264e_hip_stream_done(c->pool, slot, &r1)) == 0)
             {
                 if (!h264e_hip_busy(c->pool) && ++idle > 2) break;      /* the launch ended without finishing this job */
+                if (c->idle_hook) c->idle_hook(c->idle_token);
                 sched_yield();
             }
             if (dn == 0) dn = h264e_hip_stream_done(c->pool, slot, &r1);
@@ -962,63 +1048,76 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             if (i == 0) { t_first = t_last; far_reads = 0; }
             far_reads += r1.far_reads;
             if (r1.overflow) { snprintf(g_host_err, sizeof(g_host_err), "bit buffer overflow (frame %d)", f); (void)h264e_hip_stream_abort(c->pool); (void)h264e_hip_sync(c->pool); goto done; }
-            if (per_mb || r1.clusters_moved || used[i][0] != state[0] || used[i][1] != state[1])
+            int32_t cc[2] = { c->state[0], c->state[1] };       /* state behind this frame, committed once the frame is accepted */
+            if (per_mb || r1.clusters_moved || used[i][0] != c->state[0] || used[i][1] != c->state[1])
             {
                 /* exact walk: does every consumed (rounded) candidate equal what the kernel was given? */
-                int32_t cc[2] = { state[0], state[1] };
-                const int first_bad = clusters_walk(cc, h264e_hip_stream_mbrec(c->pool, slot), c->seq.nmbx, c->seq.nmby, nslices, per_mb ? first_arr : used[i], per_mb, traj);
-                const int bad = first_bad >= 0;
-                if (bad)
+                const int first_bad = clusters_walk(cc, h264e_hip_stream_mbrec(c->pool, slot), c->seq.nmbx, c->seq.nmby, nslices, per_mb ? c->first_arr : used[i], per_mb, c->traj);
+                if (first_bad >= 0)
                 {
                     /* every macroblock before first_bad consumed exactly the right candidates: its row and the rows above
                      * it are bit-identical in the next encode and are kept */
-                    first_row = first_bad/c->seq.nmbx;
+                    c->first_row = first_bad/c->seq.nmbx;
                     /* frames from here on are void: stop the launch, go again with exact per-macroblock values for this one */
                     if (h264e_hip_stream_abort(c->pool)) goto done;
-                    if (!first_arr) first_arr = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb);
-                    if (!first_arr) goto done;
-                    memcpy(first_arr, traj, sizeof(int32_t)*2*(size_t)nmb);
-                    after[0] = cc[0]; after[1] = cc[1]; have_after = 1;     /* the walk's end: what this frame most likely leaves behind */
+                    if (!c->first_arr) c->first_arr = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb);
+                    if (!c->first_arr) goto done;
+                    memcpy(c->first_arr, c->traj, sizeof(int32_t)*2*(size_t)nmb);
+                    c->after[0] = cc[0]; c->after[1] = cc[1]; c->have_after = 1;     /* the walk's end: what this frame most likely leaves behind */
                     stats.reencoded_gops++;             /* counts relaunches */
                     break;
                 }
-                state[0] = cc[0]; state[1] = cc[1];
             }
-            if (i == 0 && first_arr) { free(first_arr); first_arr = NULL; }
             t0 = now_ms();
             {
-                const uint8_t *rb = h264e_hip_stream_rbsp(c->pool, slot);
-                size_t start = pos, w;
-                if (key)
+                /* the frame as the kernel exported it: complete NALs (start codes and emulation prevention done on the device) */
+                const uint8_t *nals = h264e_hip_stream_rbsp(c->pool, slot);
+                size_t start = pos, w = 0, need = (key ? 64 : 0) + r1.nbytes;
+                if (pos + need > cap)
                 {
-                    if (pos + 64 > cap) { snprintf(g_host_err, sizeof(g_host_err), "output buffer too small"); (void)h264e_hip_sync(c->pool); goto done; }
-                    pos += write_sps_pps(&c->seq, pic_init_qp, out + pos, NULL, NULL);
+                    /* the caller's buffer is full: stop here, the stream continues with this frame in the next call */
+                    if (h264e_hip_stream_abort(c->pool)) goto done;
+                    full = 1;
+                    break;
                 }
-                w = emit_slices(out + pos, cap - pos, rb, &r1, NULL, NULL);
-                if (!w) { snprintf(g_host_err, sizeof(g_host_err), "output buffer too small"); (void)h264e_hip_stream_abort(c->pool); (void)h264e_hip_sync(c->pool); goto done; }
+                if (key) pos += write_sps_pps(&c->seq, pic_init_qp, out + pos, NULL, NULL);
+                w = emit_slices(out + pos, cap - pos, nals, &r1, NULL, NULL);
+                if (!w) { snprintf(g_host_err, sizeof(g_host_err), "malformed frame export"); (void)h264e_hip_stream_abort(c->pool); (void)h264e_hip_sync(c->pool); goto done; }
                 pos += w;
-                if (frame_bytes) frame_bytes[f] = (int)(pos - start);
-                if (rc_on) rc_frame_end(&rcs, nmb, c->par.vbv_size_bytes, desired_frame_bytes, (int)(pos - start), key, r1.all_skipped);
+                if (frame_bytes) frame_bytes[f - first] = (int)(pos - start);
+                if (rc_on) rc_frame_end(&c->rcs, nmb, c->par.vbv_size_bytes, desired_frame_bytes, (int)(pos - start), key, r1.all_skipped);
             }
+            c->state[0] = cc[0]; c->state[1] = cc[1];
+            if (i == 0 && c->first_arr) { free(c->first_arr); c->first_arr = NULL; }
             stats.assemble_ms += now_ms() - t0;
             nvalid++;
         }
         if (h264e_hip_sync(c->pool)) goto done;         /* the launch has drained (immediately after an abort) */
-        stats.encode_ms += now_ms() - t0;
-        n += nvalid;
+        stats.encode_ms += now_ms() - t_submit;
+        if (c->ssd_out && nvalid)
+        {
+            /* device-side sums of squared differences of the frames just validated: their pictures are still in their slots */
+            if (h264e_hip_ssd_frames(c->pool, nvalid, n % c->resident, c->resident, n % K, K, c->ssd_out + 3*(size_t)(n - first))) goto done;
+        }
+        c->next = n + nvalid;
         /* more than one macroblock in eight left the narrow window: the wide one pays from here on */
-        if (narrow && nvalid > 0 && far_reads > (long long)nvalid*nmb/8) narrow = 0;
+        if (c->narrow && nvalid > 0 && far_reads > (long long)nvalid*nmb/8) c->narrow = 0;
         if (getenv("H264E_DEBUG"))
             fprintf(stderr, "clip launch %d (first row %d, %s window, %lld far reads): %d frames in flight, %d valid, next %d; first frame after %.2f ms, then %.3f ms/frame, drained %.2f ms after the last\n",
-                    stats.rounds, tasks[0].first_row, tasks[0].narrow_window ? "narrow" : "wide", far_reads, F, nvalid, n, t_first - t_submit, nvalid > 1 ? (t_last - t_first)/(nvalid - 1 + (nvalid < F)) : 0.0, now_ms() - t_last);
+                    stats.rounds, tasks[0].first_row, tasks[0].narrow_window ? "narrow" : "wide", far_reads, F, nvalid, c->next, t_first - t_submit, nvalid > 1 ? (t_last - t_first)/(nvalid - 1 + (nvalid < F)) : 0.0, now_ms() - t_last);
+        if (full && c->next == first)
+        {
+            snprintf(g_host_err, sizeof(g_host_err), "output buffer too small for one frame");
+            goto done;
+        }
     }
-    stats.mv_clusters_out[0] = state[0]; stats.mv_clusters_out[1] = state[1];
-    stats.next_idr_pic_id_state = idr_state ^ (((c->nframes + G - 1)/G) & 1);
+    stats.frames = c->next - first;
+    stats.mv_clusters_out[0] = c->state[0]; stats.mv_clusters_out[1] = c->state[1];
+    stats.next_idr_pic_id_state = idr_state ^ (((c->next + G - 1)/G) & 1);
     h264e_hip_profile_read(c->pool, &stats.mb_kernel_ms, &stats.splice_kernel_ms, &stats.kernel_launches);
     if (out_bytes) *out_bytes = pos;
     rc = 0;
 done:
     if (st) *st = stats;
-    free(tasks); free(flags); free(used); free(rec); free(traj); free(rbsp); free(first_arr);
     return rc;
 }

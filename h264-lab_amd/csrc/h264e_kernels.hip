@@ -95,17 +95,20 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            export_frame(G, C, T);
+            uint32_t nal_bytes[H264E_MAX_SLICES], nal_total = 0;
+            int exp_overflow = 0;
+            export_frame(G, C, T, nal_bytes, nal_total, exp_overflow);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0)
             {
                 const GLOBAL_AS h264e_frameout_t &F = C.fout[T.frame_slot];
                 GLOBAL_AS h264e_hostdone_t *hd = (GLOBAL_AS h264e_hostdone_t *)T.host_done;
-                hd->nbytes = F.nbytes; hd->all_skipped = F.all_skipped;
+                hd->nbytes = nal_total; hd->all_skipped = F.all_skipped;
                 hd->nslices = F.nslices;
-                for (int k = 0; k < H264E_MAX_SLICES; k++) hd->slice_nbytes[k] = F.slice_nbytes[k];
-                hd->clusters_moved = F.clusters_moved; hd->overflow = F.overflow; hd->far_reads = F.far_reads;
+#pragma unroll
+                for (int k = 0; k < H264E_MAX_SLICES; k++) hd->slice_nbytes[k] = nal_bytes[k];
+                hd->clusters_moved = F.clusters_moved; hd->overflow = F.overflow | exp_overflow; hd->far_reads = F.far_reads;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                 /* system scope: the host reads these */
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(&hd->done, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -207,6 +210,15 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
 
 #endif
 
+#ifndef H264E_EMU
+__global__ void __launch_bounds__(64) h264e_nal_escape_selftest_kernel(uint8_t *dst, uint32_t cap, const uint8_t *src, uint32_t n, uint32_t *out)
+{
+    int overflow = 0;
+    const uint32_t w = nal_escape_copy((GLOBAL_AS uint8_t *)dst, cap, (const GLOBAL_AS uint8_t *)src, n, overflow);
+    if (threadIdx.x == 0) { out[0] = w; out[1] = (uint32_t)overflow; }
+}
+#endif
+
 /* synth_v1 generator, one sample per call */
 DEV uint32_t sv_h32(uint32_t a)
 {
@@ -299,6 +311,7 @@ struct h264e_hip_pool
     h264e_hip_mbrec_t **host_mbrec;      /* [nchains], each nmb records */
     uint32_t host_rbsp_cap;
     int *abort_word;                     /* host-mapped */
+    unsigned long long *ssd_dev;         /* [nchains][3] sums of squared differences (h264e_hip_ssd_frames) */
     uint8_t *heap; size_t heap_bytes;    /* ONE device allocation; every device buffer of the pool is carved out of it */
     uint8_t *hheap; size_t hheap_bytes;  /* ONE host-mapped allocation for the streaming mirrors */
     int launch_counter;
@@ -310,6 +323,7 @@ struct h264e_hip_pool
     double prof_mb_ms, prof_splice_ms;
 #ifndef H264E_EMU
     hipStream_t stream;
+    hipStream_t copy_stream;             /* uploads that overlap with kernels on `stream` */
     hipEvent_t ev_t0, ev_t1;
     hipEvent_t ev[TASK_RING][3];         /* per pending submit: before / between / after the two kernels */
     int ev_pending;
@@ -333,6 +347,7 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
 #ifndef H264E_EMU
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->copy_stream) (void)hipStreamSynchronize(p->copy_stream);
 #endif
     host_free(p->hheap);
     free(p->host_rbsp); free(p->host_mbrec); free(p->slot_launch);
@@ -343,6 +358,7 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
         for (int i = 0; i < TASK_RING; i++) for (int k = 0; k < 3; k++) (void)hipEventDestroy(p->ev[i][k]);
         (void)hipEventDestroy(p->ev_t0); (void)hipEventDestroy(p->ev_t1);
         (void)hipStreamDestroy(p->stream);
+        if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     }
 #endif
     free(p->chains_host); free(p->clu_dev); free(p->ref_sel);
@@ -374,7 +390,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         FAIL("no HIP device: the HIP path is mandatory (there is no CPU fallback)");
     }
     if (hipSetDevice(device) != hipSuccess) { free(p); FAIL("hipSetDevice(%d) failed", device); }
-    if (hipStreamCreate(&p->stream) != hipSuccess) { free(p); FAIL("hipStreamCreate failed"); }
+    if (hipStreamCreate(&p->stream) != hipSuccess || hipStreamCreate(&p->copy_stream) != hipSuccess) { free(p); FAIL("hipStreamCreate failed"); }
     for (int i = 0; i < TASK_RING; i++) for (int k = 0; k < 3; k++) (void)hipEventCreate(&p->ev[i][k]);
     (void)hipEventCreate(&p->ev_t0); (void)hipEventCreate(&p->ev_t1);
 #endif
@@ -403,6 +419,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         p->progress_all = (int *)carve(sizeof(int)*(size_t)nchains*G.nmby, 256);
         p->errflag = (int *)carve(sizeof(int), 256);
         p->stepflags = (int *)carve(sizeof(int)*2*(size_t)nchains, 256);
+        p->ssd_dev = (unsigned long long *)carve(sizeof(unsigned long long)*3*(size_t)nchains, 256);
         p->order = (uint32_t *)carve(sizeof(uint32_t)*2*(size_t)nchains*(G.nmby + 1), 256);
         p->host_done = (h264e_hostdone_t *)hcarve(sizeof(h264e_hostdone_t)*(size_t)nchains);
         p->abort_word = (int *)hcarve(64);
@@ -491,6 +508,119 @@ extern "C" int h264e_hip_upload_i420(h264e_hip_pool_t *p, int first, int nframes
 #else
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipMemcpyAsync(p->clip + p->frame_bytes*(size_t)first, host, p->frame_bytes*(size_t)nframes, hipMemcpyHostToDevice, p->stream));
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_upload_i420_async(h264e_hip_pool_t *p, int first, int nframes, const uint8_t *host)
+{
+    if (!p || first < 0 || nframes < 0 || first + nframes > p->frames_resident) FAIL("upload_i420_async: bad range");
+#ifdef H264E_EMU
+    memcpy(p->clip + p->frame_bytes*(size_t)first, host, p->frame_bytes*(size_t)nframes);
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpyAsync(p->clip + p->frame_bytes*(size_t)first, host, p->frame_bytes*(size_t)nframes, hipMemcpyHostToDevice, p->copy_stream));
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_upload_wait(h264e_hip_pool_t *p)
+{
+    if (!p) FAIL("upload_wait: null pool");
+#ifndef H264E_EMU
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->copy_stream));
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_upload_busy(h264e_hip_pool_t *p)
+{
+#ifdef H264E_EMU
+    (void)p;
+    return 0;
+#else
+    if (!p) return 0;
+    (void)hipSetDevice(p->device);
+    return hipStreamQuery(p->copy_stream) == hipErrorNotReady;
+#endif
+}
+
+extern "C" void *h264e_hip_host_alloc(size_t bytes)
+{
+#ifdef H264E_EMU
+    return malloc(bytes ? bytes : 1);
+#else
+    void *q = 0;
+    return hipHostMalloc(&q, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? q : 0;
+#endif
+}
+
+extern "C" void h264e_hip_host_free(void *q)
+{
+#ifdef H264E_EMU
+    free(q);
+#else
+    if (q) (void)hipHostFree(q);
+#endif
+}
+
+#ifndef H264E_EMU
+/* sum of squared differences of one plane pair; grid.y = frame, grid.z = plane, grid.x strides over the samples */
+__global__ void h264e_ssd_kernel(const uint8_t *clip, size_t frame_bytes, int width, int height, int in0, int in_mod,
+                                 const h264e_chain_dev_t *chains, int pic0, int pic_mod, int W, unsigned long long *out)
+{
+    const int i = (int)blockIdx.y, pl = (int)blockIdx.z;
+    const int w = width >> (pl ? 1 : 0), h = height >> (pl ? 1 : 0), ps = W >> (pl ? 1 : 0);
+    const uint8_t *a = clip + frame_bytes*(size_t)((in0 + i) % in_mod) + (pl ? (size_t)width*height + (pl == 2 ? (size_t)(width/2)*(height/2) : 0) : 0);
+    const uint8_t *b = chains[(pic0 + i) % pic_mod].rec[0][pl];
+    unsigned long long s = 0;
+    for (int k = (int)(blockIdx.x*blockDim.x + threadIdx.x); k < w*h; k += (int)(gridDim.x*blockDim.x))
+    {
+        const int y = k / w, x = k - y*w, d = (int)a[k] - (int)b[(size_t)y*ps + x];
+        s += (unsigned long long)(d*d);
+    }
+    for (int o = 32; o; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out + 3*i + pl, s);
+}
+#endif
+
+extern "C" int h264e_hip_ssd_frames(h264e_hip_pool_t *p, int n, int in0, int in_mod, int pic0, int pic_mod, uint64_t *out)
+{
+    if (!p || !out || n <= 0 || n > p->nchains || in_mod <= 0 || in_mod > p->frames_resident || pic_mod <= 0 || pic_mod > p->nchains) FAIL("ssd_frames: bad argument");
+    const h264e_geom_t &G = p->G;
+#ifdef H264E_EMU
+    for (int i = 0; i < n; i++)
+        for (int pl = 0; pl < 3; pl++)
+        {
+            const int w = G.width >> (pl ? 1 : 0), h = G.height >> (pl ? 1 : 0), ps = G.W >> (pl ? 1 : 0);
+            const uint8_t *a = p->clip + p->frame_bytes*(size_t)((in0 + i) % in_mod) + (pl ? (size_t)G.width*G.height + (pl == 2 ? (size_t)(G.width/2)*(G.height/2) : 0) : 0);
+            const uint8_t *b = p->chains_host[(pic0 + i) % pic_mod].rec[0][pl];
+            uint64_t s = 0;
+            for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) { const int d = (int)a[(size_t)y*w + x] - (int)b[(size_t)y*ps + x]; s += (uint64_t)(d*d); }
+            out[3*i + pl] = s;
+        }
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemsetAsync(p->ssd_dev, 0, sizeof(unsigned long long)*3*(size_t)n, p->stream));
+    hipLaunchKernelGGL(h264e_ssd_kernel, dim3(64, (unsigned)n, 3), dim3(256), 0, p->stream, (const uint8_t *)p->clip, p->frame_bytes, G.width, G.height,
+                       in0, in_mod, (const h264e_chain_dev_t *)p->chains_dev, pic0, pic_mod, G.W, p->ssd_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, p->ssd_dev, sizeof(unsigned long long)*3*(size_t)n, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_read_recon_slot(h264e_hip_pool_t *p, int slot, uint8_t *dst)
+{
+    if (!p || !dst || slot < 0 || slot >= p->nchains) FAIL("read_recon_slot: bad argument");
+    const size_t n = (size_t)p->G.W*p->G.H*3/2;
+#ifdef H264E_EMU
+    memcpy(dst, p->chains_host[slot].rec[0][0], n);
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpy(dst, p->chains_host[slot].rec[0][0], n, hipMemcpyDeviceToHost));
 #endif
     return 0;
 }
@@ -618,6 +748,17 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             for (int k = 0; k < 3; k++) { d.ref[k] = p->chains_host[c].rec[rs][k]; d.dec[k] = p->chains_host[c].rec[rs ^ 1][k]; }
             d.dep_progress = 0;
             p->ref_sel[c] ^= 1;
+            if (p->host_rbsp[c] && p->host_mbrec[c])
+            {
+                /* one result per chain (slots_per_chain == 1): the finalizer exports it to host-mapped memory like a stream job, so
+                 * the host reads NALs, flags and records without a device-to-host copy */
+                d.arena_reset = 1;
+                d.host_done = p->host_done + c;
+                d.host_rbsp = p->host_rbsp[c]; d.host_rbsp_cap = p->host_rbsp_cap;
+                d.host_mbrec = (h264e_mbrec_t *)p->host_mbrec[c];
+                p->host_done[c].done = 0;
+                p->slot_launch[c] = launch_id;
+            }
         }
         d.frame_slot = t.frame_slot;
         d.first_row = (t.stream_mode && t.first_row > 0 && t.first_row < G.nmby) ? t.first_row : 0;
@@ -680,12 +821,14 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         finalize_frame(G, C, T, p->stepflags + 2*c);
         if (T.host_done)
         {
-            export_frame(G, C, T);
+            uint32_t nal_bytes[H264E_MAX_SLICES], nal_total = 0;
+            int exp_overflow = 0;
+            export_frame(G, C, T, nal_bytes, nal_total, exp_overflow);
             const h264e_frameout_t &F = C.fout[T.frame_slot];
-            T.host_done->nbytes = F.nbytes; T.host_done->all_skipped = F.all_skipped;
+            T.host_done->nbytes = nal_total; T.host_done->all_skipped = F.all_skipped;
             T.host_done->nslices = F.nslices;
-            for (int k = 0; k < H264E_MAX_SLICES; k++) T.host_done->slice_nbytes[k] = F.slice_nbytes[k];
-            T.host_done->clusters_moved = F.clusters_moved; T.host_done->overflow = F.overflow; T.host_done->far_reads = F.far_reads;
+            for (int k = 0; k < H264E_MAX_SLICES; k++) T.host_done->slice_nbytes[k] = nal_bytes[k];
+            T.host_done->clusters_moved = F.clusters_moved; T.host_done->overflow = F.overflow | exp_overflow; T.host_done->far_reads = F.far_reads;
             T.host_done->done = T.launch_id;
         }
     }
@@ -922,6 +1065,40 @@ extern "C" int h264e_hip_rewind_frame(h264e_hip_pool_t *p, int chain, int slot)
     HIPCHK(hipMemcpyAsync(p->chains_host[chain].cursor, &p->chains_host[chain].fout[slot].offset, sizeof(uint32_t), hipMemcpyDeviceToDevice, p->stream));
 #endif
     return 0;
+}
+
+extern "C" int h264e_hip_selftest_nal_escape(h264e_hip_pool_t *p, const uint8_t *src, uint32_t n, uint8_t *dst, uint32_t cap, uint32_t *out_n)
+{
+    if (!p || !src || !dst || !out_n) FAIL("selftest_nal_escape: bad argument");
+    const size_t sb = ((size_t)n + 64 + 15) & ~(size_t)15, db = ((size_t)cap + 15) & ~(size_t)15;
+#ifdef H264E_EMU
+    uint8_t *s = (uint8_t *)calloc(1, sb), *d = (uint8_t *)calloc(1, db + 16);
+    int overflow = 0;
+    if (!s || !d) { free(s); free(d); FAIL("out of host memory"); }
+    memcpy(s, src, n);
+    *out_n = nal_escape_copy(d, cap, s, n, overflow);
+    if (!overflow) memcpy(dst, d, *out_n);
+    free(s); free(d);
+    return overflow ? 1 : 0;
+#else
+    uint8_t *buf = 0;
+    uint32_t res[2] = { 0, 0 };
+    HIPCHK(hipSetDevice(p->device));
+    if (hipMalloc((void **)&buf, sb + db + 64) != hipSuccess) FAIL("selftest_nal_escape: device allocation failed");
+    hipError_t e = hipMemset(buf, 0, sb + db + 64);
+    if (e == hipSuccess) e = hipMemcpy(buf, src, n, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+    {
+        hipLaunchKernelGGL(h264e_nal_escape_selftest_kernel, dim3(1), dim3(64), 0, p->stream, buf + sb, cap, (const uint8_t *)buf, n, (uint32_t *)(buf + sb + db));
+        e = hipStreamSynchronize(p->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(res, buf + sb + db, sizeof(res), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && !res[1] && res[0] <= cap) e = hipMemcpy(dst, buf + sb, res[0], hipMemcpyDeviceToHost);
+    (void)hipFree(buf);
+    if (e != hipSuccess) FAIL("selftest_nal_escape: %s", hipGetErrorString(e));
+    *out_n = res[0];
+    return res[1] ? 1 : 0;
+#endif
 }
 
 /* diagnostic: per-phase cycle sums of the -DH264E_STAMPS build, summed over chains (zeros in the product build) */

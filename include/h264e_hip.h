@@ -79,6 +79,13 @@ int  h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int width, int h
 void h264e_hip_pool_destroy(h264e_hip_pool_t *pool);
 /* packed I420 frames (width*height*3/2 bytes each) from host memory into resident slots first.. */
 int  h264e_hip_upload_i420(h264e_hip_pool_t *pool, int first, int nframes, const uint8_t *host_i420);
+/* the same from pinned host memory (h264e_hip_host_alloc) on the pool's copy stream, concurrently with kernels on the encode
+ * stream; h264e_hip_upload_wait() blocks until every such copy has landed */
+int  h264e_hip_upload_i420_async(h264e_hip_pool_t *pool, int first, int nframes, const uint8_t *pinned_i420);
+int  h264e_hip_upload_wait(h264e_hip_pool_t *pool);
+int  h264e_hip_upload_busy(h264e_hip_pool_t *pool);         /* 1 while such a copy is still in flight */
+void *h264e_hip_host_alloc(size_t bytes);
+void h264e_hip_host_free(void *p);
 /* one frame from three planes with arbitrary strides (the H264E_io_yuv_t of the drop-in API) */
 int  h264e_hip_upload_planes(h264e_hip_pool_t *pool, int index, const uint8_t *const yuv[3], const int stride[3]);
 /* fill resident frames [first, first+n) with the synth_v1 test clip ON THE DEVICE (bench input, already in HBM) */
@@ -106,6 +113,11 @@ int  h264e_hip_read_mbrec(h264e_hip_pool_t *pool, int chain, int slot, h264e_hip
 int  h264e_hip_read_mbrec_all(h264e_hip_pool_t *pool, int chain, int nslots, h264e_hip_mbrec_t *dst);
 /* reconstructed picture of the chain's last frame, coded size, packed I420 */
 int  h264e_hip_read_recon(h264e_hip_pool_t *pool, int chain, uint8_t *dst);
+/* stream pools: the picture of chain slot `slot` (coded size, packed I420) */
+int  h264e_hip_read_recon_slot(h264e_hip_pool_t *pool, int slot, uint8_t *dst);
+/* sums of squared differences between resident input frames and stream pictures, one small kernel per call: frame i uses input
+ * slot (in0 + i) % in_mod and picture slot (pic0 + i) % pic_mod; out = host [n][3] (Y, U, V), picture size width x height */
+int  h264e_hip_ssd_frames(h264e_hip_pool_t *pool, int n, int in0, int in_mod, int pic0, int pic_mod, uint64_t *out);
 /* forget the results of a chain (arena cursor back to 0); the reference picture is kept */
 int  h264e_hip_reset_results(h264e_hip_pool_t *pool, int chain);
 /* drop the chain's last submitted frame (result in `slot`): undo the reference/reconstruction swap and give its
@@ -119,6 +131,10 @@ int  h264e_hip_stamps_read(h264e_hip_pool_t *pool, unsigned long long *dst /* [3
 /* wall clock of a region on the pool's stream, by HIP events */
 int  h264e_hip_timer_start(h264e_hip_pool_t *pool);
 int  h264e_hip_timer_stop(h264e_hip_pool_t *pool, double *ms);
+/* self-test hook: runs the device's NAL emulation-prevention pass (enc_row.h nal_escape_copy, one wavefront) on n payload bytes;
+ * dst receives start code + escaped payload, *out_n its size.  Used by tests with adversarial inputs (real streams need an
+ * escape about once per 4 MB). */
+int  h264e_hip_selftest_nal_escape(h264e_hip_pool_t *pool, const uint8_t *src, uint32_t n, uint8_t *dst, uint32_t cap, uint32_t *out_n);
 const char *h264e_hip_last_error(void);
 
 #ifdef __cplusplus

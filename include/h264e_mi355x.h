@@ -126,6 +126,7 @@ typedef struct
     int32_t mv_clusters_in[2];              /* enc->mv_clusters before the first frame (0,0 for a fresh stream) */
     int slices;                             /* row-band slices per frame: 0 / 1 = one; N = the reference's H264E_MAX_THREADS build with --threads N */
     int kbps;                               /* 0 = constant QP `qp`; > 0 = frame-level rate control as encode_app --kbps (frames then run one per launch) */
+    int resident_frames;                    /* input frames kept in HBM (a ring, frame f in slot f % resident_frames); 0 = the whole clip */
 } H264E_clip_param_t;
 
 typedef struct
@@ -136,17 +137,38 @@ typedef struct
     int chains, rounds, reencoded_gops;                         /* frames in flight per launch, launches, relaunches after a mis-speculated mv_clusters state */
     int32_t mv_clusters_out[2];
     int next_idr_pic_id_state;
+    int first_frame, frames;                                    /* the frames this call encoded: [first_frame, first_frame + frames) */
 } H264E_clip_stats_t;
 
 typedef struct H264E_clip_tag H264E_clip_t;
-/* Create a clip encoder for nframes resident frames. */
+/* Create a clip encoder for a stream of at most nframes frames. */
 int  H264E_clip_open(H264E_clip_t **clip, const H264E_clip_param_t *par, int nframes);
-/* Input: packed I420 frames from host memory, or the synth_v1 test clip generated in HBM. */
+/* Input: packed I420 frames [first, first + nframes) of the stream from host memory, or the synth_v1 test clip generated in HBM.
+ * With a bounded input ring (resident_frames) a frame can be uploaded once frame (f - resident_frames) has been encoded. */
 int  H264E_clip_upload(H264E_clip_t *clip, int first, int nframes, const uint8_t *i420);
 int  H264E_clip_generate_synth(H264E_clip_t *clip, int first, int nframes, int t0, uint32_t seed);
-/* Encode all resident frames; out receives the Annex-B stream. profile != 0 adds per-kernel HIP-event timing. */
-int  H264E_clip_encode(H264E_clip_t *clip, uint8_t *out, size_t cap, size_t *out_bytes, int *frame_bytes /* [nframes] or NULL */,
+/* the same from pinned host memory on the copy engine, overlapping with a running encode; H264E_clip_upload_wait() completes it */
+void *H264E_clip_host_alloc(size_t bytes);
+void  H264E_clip_host_free(void *p);
+int  H264E_clip_upload_async(H264E_clip_t *clip, int first, int nframes, const uint8_t *pinned_i420);
+int  H264E_clip_upload_wait(H264E_clip_t *clip);
+int  H264E_clip_upload_poll(H264E_clip_t *clip);              /* 1 = landed (frames count as uploaded), 0 = still copying */
+/* where the stream stands: next frame to encode, frames uploaded so far */
+void H264E_clip_position(const H264E_clip_t *clip, int *next_frame, int *uploaded_frames);
+/* called (from the calling thread) while H264E_clip_encode waits for the GPU: a file-fed application issues and completes its
+ * uploads from here, so that frames keep arriving while earlier ones are being encoded */
+void H264E_clip_set_idle_hook(H264E_clip_t *clip, void (*hook)(void *token), void *token);
+/* Encode the frames uploaded so far and not yet encoded -- or as many of them as fit `out` -- and append their Annex-B bytes;
+ * stats->first_frame / frames say which; frame_bytes[i] is the size of frame first_frame + i.  The stream continues with the
+ * next call.  profile != 0 adds per-kernel HIP-event timing. */
+int  H264E_clip_encode(H264E_clip_t *clip, uint8_t *out, size_t cap, size_t *out_bytes, int *frame_bytes /* [frames of this call] or NULL */,
                        int profile, H264E_clip_stats_t *stats);
+/* back to frame 0 with the stream state of H264E_clip_open (the uploaded frames stay): encode the clip again */
+void H264E_clip_rewind(H264E_clip_t *clip);
+/* reconstruction (coded size, packed I420) of one of the last frames encoded (its picture slot must not have been reused) */
+int  H264E_clip_read_recon(H264E_clip_t *clip, int frame, uint8_t *dst);
+/* per encoded frame [3] sums of squared differences input vs reconstruction (Y, U, V), computed on the device: encode_app --psnr */
+void H264E_clip_set_ssd_output(H264E_clip_t *clip, uint64_t *ssd);
 void H264E_clip_close(H264E_clip_t *clip);
 /* diagnostic: per-phase cycle sums [32] of a -DH264E_STAMPS kernel build since the last call (zeros in the product) */
 int  H264E_clip_stamps(H264E_clip_t *clip, unsigned long long *dst);

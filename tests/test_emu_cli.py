@@ -1,0 +1,56 @@
+"""CPU: the product CLI (encode_app.c) linked against the test-only emulation library: the file pipeline of --clip 1 -- reader
+thread, two staging buffers, input ring in "HBM", bounded output buffer, device-side PSNR sums -- on tiny clips with budgets
+small enough that the ring wraps and the output buffer fills many times."""
+import os
+import subprocess
+
+import pytest
+
+import clips
+import oracle_lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+APP = os.path.join(HERE, "emu", "build", "encode_app_emu")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _emu():
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "emu")], stdout=subprocess.DEVNULL)
+
+
+@pytest.mark.parametrize("flags,kw", [("--qp 26 --gop 7", dict(gop=7, qp=26)), ("--qp 30 --gop 7 --threads 3", dict(gop=7, qp=30, slices=3)),
+                                      ("--kbps 200 --gop 30", dict(gop=30, kbps=200))])
+def test_clip_pipeline_bounded_buffers(tmp_path, flags, kw):
+    w, h, n = 176, 144, 40
+    c = clips.make("synth", w, h, n)
+    yuv = tmp_path / ("app_%dx%d.yuv" % (w, h))
+    c.tofile(yuv)
+    fsz = w * h * 3 // 2
+    want, sizes = oracle_lib.encode_clip(c, w, h, **kw)
+    env = dict(os.environ, H264E_APP_STAGE_KB=str(fsz * 3 // 1024 + 1), H264E_APP_RING_KB=str(fsz * 12 // 1024), H264E_APP_OUT_KB="8")
+    out = tmp_path / "o.264"
+    r = subprocess.run([APP, "--input", str(yuv), "--output", str(out), "--clip", "1", "--stats", "x"] + flags.split(), env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert out.read_bytes() == want
+    assert [l for l in r.stdout.splitlines() if l.startswith("frame=")] == ["frame=%d, bytes=%d" % (i, b) for i, b in enumerate(sizes)]
+    assert "input ring 12 frames, staging 2 x 3 frames" in r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(oracle_lib.REF_APP), reason="compiled reference (oracle/_ref) not present")
+def test_psnr_line_equals_reference(tmp_path):
+    """--psnr: same stdout line as the reference (minih264e_test.c:376-405), in clip mode from device-side sums of squared
+    differences, in frame-at-a-time mode from the reconstruction written back into the input planes (h264-lab.h:6719-6723)"""
+    w, h, n = 176, 144, 12
+    c = clips.make("synth", w, h, n)
+    yuv = tmp_path / ("app_%dx%d.yuv" % (w, h))
+    c.tofile(yuv)
+    flags = ["--qp", "26", "--gop", "5", "--psnr", "x"]
+    ref = subprocess.run([oracle_lib.REF_APP, "--input", str(yuv), "--output", str(tmp_path / "r.264")] + flags, capture_output=True, text=True)
+    line = [l for l in ref.stdout.splitlines() if "YPSNR" in l]
+    assert len(line) == 1
+    for extra in ([], ["--clip", "1"]):
+        r = subprocess.run([APP, "--input", str(yuv), "--output", str(tmp_path / "o.264")] + flags + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert [l for l in r.stdout.splitlines() if "YPSNR" in l] == line
+        assert (tmp_path / "o.264").read_bytes() == (tmp_path / "r.264").read_bytes()

@@ -134,3 +134,25 @@ def test_clip_encoder_rate_control(name, w, h, n, gop, kbps, slices):
     out, fs, _ = ce.encode()
     ce.close()
     assert out == want and fs == sizes
+
+
+def test_nal_escape_pass_on_adversarial_payloads():
+    """the device's emulation-prevention pass (whole-wave copy of blocks without a 00 00 0x triple, byte automaton for the
+    others) against the reference's automaton: zero runs, triples across block edges, zero-rich random data"""
+    import ctypes as C
+    import nal_cases
+    P = pkg.load_pkg()
+    L = P.load(pkg.EMU_LIB)
+    L.h264e_hip_pool_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.h264e_hip_selftest_nal_escape.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.h264e_hip_pool_destroy.argtypes = [C.c_void_p]
+    pool = C.c_void_p()
+    assert L.h264e_hip_pool_create(C.byref(pool), 0, 64, 48, 1, 1, 1) == 0
+    for p in nal_cases.cases():
+        want = nal_cases.escape_ref(p)
+        cap = len(p) * 3 // 2 + 64
+        dst = C.create_string_buffer(cap)
+        n = C.c_uint32()
+        assert L.h264e_hip_selftest_nal_escape(pool, p, len(p), dst, cap, C.byref(n)) == 0
+        assert dst.raw[: n.value] == want, (len(p), p[:16])
+    L.h264e_hip_pool_destroy(pool)

@@ -58,3 +58,64 @@ def test_cli_clip_mode_and_quirks(app, tmp_path):
     # unopenable input
     r = _run(["--input", str(tmp_path / "missing_352x288.yuv"), "--output", str(out)], str(tmp_path))
     assert r.returncode == 1 and b"cant open input file" in r.stdout
+
+
+GOLDEN_BIG = json.load(open(os.path.join(HERE, "golden", "golden_big.json")))
+SYNTH = os.path.join(os.path.dirname(HERE), "oracle", "build", "synth_v1")
+
+
+def _synth_file(tmp_path, w, h, n):
+    if not os.path.exists(SYNTH):
+        subprocess.check_call(["make", "-C", os.path.join(os.path.dirname(HERE), "oracle"), "all"], stdout=subprocess.DEVNULL)
+    yuv = tmp_path / ("sv1_%dx%d.yuv" % (w, h))
+    subprocess.check_call([SYNTH, str(w), str(h), str(n), str(yuv)])
+    return yuv
+
+
+@pytest.mark.parametrize("name,extra", [("cif_300_gop30", []), ("cif_30_thr4", []), ("cif_60_kbps", []), ("1080p_30_thr8", [])])
+def test_cli_clip_pipeline_full_length(app, tmp_path, name, extra):
+    """--clip 1: the file streams through staging buffers and the HBM input ring (small budgets here, so both wrap) -- with
+    --threads and --kbps too -- and the output equals the reference's full-length stream"""
+    g = GOLDEN_BIG[name]
+    yuv = _synth_file(tmp_path, g["w"], g["h"], g["frames"])
+    fsz = g["w"] * g["h"] * 3 // 2
+    env = dict(os.environ, H264E_APP_STAGE_KB=str(fsz * 7 // 1024 + 1), H264E_APP_RING_KB=str(fsz * 28 // 1024), H264E_APP_OUT_KB="512")
+    out = tmp_path / "o.264"
+    r = subprocess.run([APP, "--input", str(yuv), "--output", str(out), "--clip", "1", "--stats", "x"] + g["flags"].split() + extra, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = r.stdout.decode()
+    assert r.returncode == 0, text
+    assert hashlib.md5(out.read_bytes()).hexdigest() == g["md5"]
+    assert [l for l in text.splitlines() if l.startswith("frame=")] == ["frame=%d, bytes=%d" % (i, b) for i, b in enumerate(g["frame_bytes"])]
+
+
+def test_cli_4k_file_bounded_host_memory(app, tmp_path):
+    """a 4K file through --clip 1 with the default budgets: output equals the reference's stream, and the process stays under
+    2 GB of resident host memory (two pinned staging buffers + one output buffer, whatever the length of the file)"""
+    g = GOLDEN_BIG["4k_30"]
+    yuv = _synth_file(tmp_path, g["w"], g["h"], g["frames"])
+    out = tmp_path / "o.264"
+    r = subprocess.run(["/usr/bin/time", "-v", APP, "--input", str(yuv), "--output", str(out), "--clip", "1"] + g["flags"].split(),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = r.stdout.decode()
+    assert r.returncode == 0, text
+    assert hashlib.md5(out.read_bytes()).hexdigest() == g["md5"]
+    rss_kb = [int(l.split(":")[1]) for l in text.splitlines() if "Maximum resident set size" in l]
+    assert rss_kb and rss_kb[0] < 2 * 1024 * 1024, text
+
+
+def test_cli_psnr_clip_mode_equals_frame_mode(app, tmp_path):
+    """--psnr in clip mode (device-side sums of squared differences) prints the line the frame-at-a-time mode prints (which the
+    CPU suite pins against the reference binary)"""
+    g = GOLDEN[0]
+    c = clips.make(g["clip"], g["w"], g["h"], g["frames"])
+    yuv = tmp_path / ("clip_%dx%d.yuv" % (g["w"], g["h"]))
+    yuv.write_bytes(c.tobytes())
+    lines = []
+    for extra in ([], ["--clip", "1"]):
+        r = _run(["--input", str(yuv), "--output", str(tmp_path / "o.264")] + g["flags"].split() + ["--psnr", "x"] + extra, str(tmp_path))
+        assert r.returncode == 0, r.stdout.decode()
+        lines.append([l for l in r.stdout.decode().splitlines() if "YPSNR" in l])
+        assert hashlib.md5((tmp_path / "o.264").read_bytes()).hexdigest() == g["md5"]
+    assert lines[0] == lines[1] and len(lines[0]) == 1
+    assert "YPSNR=40.84 db  UPSNR=45.54 db  VPSNR=46.88 db" in lines[0][0]      # SURVEY.md Appendix B, the reference's own line

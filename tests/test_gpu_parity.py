@@ -234,3 +234,48 @@ def test_large_vertical_motion_far_reads(P, w, h, n, dy):
     out, fs, _ = ce.encode()
     ce.close()
     assert fs == sizes and out == want
+
+
+def test_nal_escape_pass_on_adversarial_payloads(P):
+    """the device's emulation-prevention pass against the reference's automaton (h264-lab.h:3926-3975) on zero runs, triples that
+    straddle the 256-byte block edges and zero-rich random data (real streams need an escape about once per 4 MB)"""
+    import ctypes as C
+    import nal_cases
+    L = P.load()
+    L.h264e_hip_pool_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.h264e_hip_selftest_nal_escape.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.h264e_hip_pool_destroy.argtypes = [C.c_void_p]
+    pool = C.c_void_p()
+    assert L.h264e_hip_pool_create(C.byref(pool), 0, 64, 48, 1, 1, 1) == 0
+    for p in nal_cases.cases():
+        want = nal_cases.escape_ref(p)
+        cap = len(p) * 3 // 2 + 64
+        dst = C.create_string_buffer(cap)
+        n = C.c_uint32()
+        assert L.h264e_hip_selftest_nal_escape(pool, p, len(p), dst, cap, C.byref(n)) == 0
+        assert dst.raw[: n.value] == want, (len(p), p[:16])
+    L.h264e_hip_pool_destroy(pool)
+
+
+def test_clip_encoder_resumes_across_calls_and_reads_recon(P):
+    """the clip encoder keeps its stream state between calls: frames uploaded in three instalments through a 9-frame input ring,
+    a small output buffer that fills -- same bytes as one pass; the reconstruction of the last frame equals the oracle's"""
+    w, h, n, gop = 352, 288, 20, 6
+    c = clips.make("pan", w, h, n)
+    want, sizes = oracle_lib.encode_clip(c, w, h, gop=gop, qp=28)
+    ce = P.ClipEncoder(w, h, n, gop=gop, qp=28, resident=9, max_chains=5)
+    out, fs = b"", []
+    for a, b in ((0, 7), (7, 13), (13, 20)):
+        ce.upload(c[a:b], first=a)
+        while len(fs) < b:
+            o, s, st = ce.encode(rewind=False, cap=40000)
+            assert st.frames > 0
+            out += o
+            fs += s
+    assert fs == sizes and out == want
+    o = oracle_lib.Encoder(w, h, gop=gop, qp=28)
+    for t in range(n):
+        o.encode(c[t])
+    rec, cw, ch = o.recon()
+    assert np.array_equal(ce.read_recon(n - 1), rec)
+    ce.close()
