@@ -4,14 +4,22 @@
 A step = one pass of the encode path over one batch: a synthetic 1920x1080 I420 clip of 600 frames (synth_v1,
 generated in HBM before the timed region), IPPP GOP 30, QP 26, speed 0 (BASELINE.json configs[2]).  Consecutive frames
 run as a temporal wavefront inside one kernel launch (a P frame starts once its reference frame is a few macroblock
-rows ahead); finished frames are exported to host-mapped memory by the kernel and validated / NAL-assembled by the
-host while the launch is still running (DESIGN.md sections 4-5).  The timed region covers everything after the input
-is resident: all kernel launches incl. the relaunches after a mis-speculated mv_clusters state, the export of the
-coded slices, host NAL assembly into the final Annex-B stream.
-With --gpus N (launched by torch.distributed.run) every rank encodes its own clip on its own GPU: clips are
+rows ahead); finished frames are spliced, NAL-escaped and exported to host-mapped memory by the kernel, validated
+(mv_clusters speculation) and appended to the Annex-B stream by the host while the launch is still running (DESIGN.md
+sections 4-5).  The timed region covers everything after the input is resident: all kernel launches incl. the relaunches
+after a mis-speculated mv_clusters state, the export of the coded slices, the host-side stream assembly.
+The md5 of the timed output is compared with the md5 of the REFERENCE encoder's stream for the same clip
+(tests/golden/golden_big.json: `parity_full_stream`).
+
+--gpus N (launched by torch.distributed.run): by default every rank encodes its own clip on its own GPU -- clips are
 independent, no data-path collective (weak scaling); torch.distributed only provides the barrier and the max-reduce.
+--shard stream: the ranks encode contiguous GOP blocks of ONE stream instead (strong scaling): every rank starts from a
+speculated mv_clusters state, the exact state is handed down the ranks (8 bytes per boundary through torch.distributed),
+each rank re-validates and encodes again from the first GOP that consumed different start candidates
+(h264-lab_amd/shard.py).
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -28,17 +36,43 @@ NMB = ((W + 15) // 16) * ((H + 15) // 16)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # algorithmic bytes per macroblock: input 384 B; P frames also read the co-located reference
 # (384 B); every frame writes 384 B of reconstruction
-BYTES_I, BYTES_P = 384 + 384, 768 + 384
+READ_I, READ_P, WRITE = 384, 768, 384
+PROFILE_TAG = "r02"
 
 
 def _pmc_traffic():
-    """HBM bytes per h264e_mb_kernel launch from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in
-    separate runs of this same command; profiles/r01_pmc_traffic.json says how they were taken), or None"""
+    """HBM bytes per h264e_mb_kernel launch from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate
+    runs of this same command; the json says how they were taken).  STATIC: read from profiles/, not measured in this run."""
+    for tag in (PROFILE_TAG, "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)) as f:
+                return json.load(f)["bytes_per_launch"], "static_from_profiles/%s_pmc_traffic.json" % tag
+        except Exception:
+            continue
+    return None, None
+
+
+def _issue_counters():
+    """SQ instruction counters of the committed profile (tools/pmc_insts.sh), for the issue roofline; static like the traffic"""
+    for tag in (PROFILE_TAG, "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", "%s_sq_counters.json" % tag)) as f:
+                return json.load(f), "static_from_profiles/%s_sq_counters.json" % tag
+        except Exception:
+            continue
+    return None, None
+
+
+def _golden_md5(w, h, frames, gop, qp):
+    """md5 of the REFERENCE encoder's stream for this clip, when tests/golden/golden_big.json holds it"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)["bytes_per_launch"]
+        with open(os.path.join(ROOT, "tests", "golden", "golden_big.json")) as f:
+            for g in json.load(f).values():
+                if (g["w"], g["h"], g["frames"], g["flags"]) == (w, h, frames, "--qp %d --gop %d" % (qp, gop)):
+                    return g["md5"]
     except Exception:
-        return None
+        pass
+    return None
 
 
 def cpu_baseline(sample_frames=60):
@@ -91,26 +125,83 @@ def cpu_baseline(sample_frames=60):
     return res, ref_bytes
 
 
+def dropin_api_fps(P, frames=12):
+    """the reference's per-frame API (H264E_encode: upload, one launch, result back before the next frame) on the same clip"""
+    import oracle_lib
+    c = oracle_lib.synth_c(W, H, frames)
+    e = P.Encoder(W, H, gop=GOP, qp=QP)
+    e.encode(c[0])
+    t0 = time.time()
+    for t in range(1, frames):
+        e.encode(c[t])
+    dt = time.time() - t0
+    e.close()
+    return (frames - 1) / dt
+
+
+def e2e_pass(P, enc, frames, w, h):
+    """one pass that also pays for the upload: the clip lies in pinned host memory, goes over PCIe in the timed region"""
+    import ctypes as C
+    import numpy as np
+    import oracle_lib
+    L = enc.L
+    L.H264E_clip_host_alloc.restype = C.c_void_p
+    L.H264E_clip_host_alloc.argtypes = [C.c_size_t]
+    L.H264E_clip_host_free.argtypes = [C.c_void_p]
+    L.H264E_clip_upload_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.H264E_clip_upload_wait.argtypes = [C.c_void_p]
+    fsz = w * h * 3 // 2
+    n = min(frames, 120)                    # 120 frames of pinned memory, uploaded chunk-wise, repeated content is fine for timing
+    p = L.H264E_clip_host_alloc(fsz * n)
+    if not p:
+        return None
+    buf = np.ctypeslib.as_array((C.c_uint8 * (fsz * n)).from_address(p))
+    for t in range(n):
+        oracle_lib.lib().synth_v1_frame(buf[t * fsz:].ctypes.data, w, h, t, 1)
+    t0 = time.time()
+    for a in range(0, frames, n):
+        k = min(n, frames - a)
+        L.H264E_clip_upload_async(enc.c, a, k, p)
+        L.H264E_clip_upload_wait(enc.c)
+    up = time.time() - t0
+    out, sizes, st = enc.encode()
+    dt = time.time() - t0
+    L.H264E_clip_host_free(p)
+    enc.generate_synth(0, frames, t0=0, seed=1)          # restore the real clip
+    return {"fps": frames / dt, "macroblocks_per_s": frames * ((w + 15) // 16) * ((h + 15) // 16) / dt, "upload_s": up,
+            "note": "upload of the whole clip from pinned host memory (serialized in front of the encode: an upper bound on the PCIe cost), then one pass"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--shard", choices=["clips", "stream"], default="clips",
+                    help="clips: every rank its own clip (weak scaling, default); stream: the ranks encode GOP blocks of ONE stream (strong scaling)")
+    ap.add_argument("--slices", type=int, default=0, help="row-band slices per frame (the reference's --threads build); default one slice")
     ap.add_argument("--frames", type=int, default=FRAMES, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-extras", action="store_true", help=argparse.SUPPRESS)
     # used only by tests/test_multirank.py to run the N > 1 path on CPU: gloo instead of RCCL, the lane-loop emulation library
     # of tests/emu instead of the GPU library, a tiny picture
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--size", default="%dx%d" % (W, H), help=argparse.SUPPRESS)
+    ap.add_argument("--gop", type=int, default=GOP, help=argparse.SUPPRESS)
     a = ap.parse_args()
     w, h = (int(v) for v in a.size.split("x"))
     nmb = ((w + 15) // 16) * ((h + 15) // 16)
     on_gpu = a.backend == "nccl"
+    gop = a.gop
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        # --gpus N without the launcher's environment would silently run one rank: refuse instead
+        sys.exit("bench.py --gpus %d needs %d ranks (WORLD_SIZE=%d): launch with python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." %
+                 (a.gpus, a.gpus, world, a.gpus, a.gpus))
     import torch
     dist = None
     if world > 1:
@@ -120,13 +211,25 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(a.backend)
+    tdev = "cuda" if on_gpu else "cpu"
 
     from __graft_entry__ import _pkg
     P = _pkg()
     frames = a.frames
     kw = {"lib": a.lib} if a.lib else {}
-    enc = P.ClipEncoder(w, h, frames, gop=GOP, qp=QP, speed=0, device=local_rank if on_gpu else 0, **kw)
-    enc.generate_synth(0, frames, t0=rank * frames, seed=1)   # every rank its own clip (weak scaling)
+    dev = local_rank if on_gpu else 0
+    stream_mode = a.shard == "stream" and world > 1
+    if stream_mode:
+        # ONE stream of `frames` frames: this rank's GOP block
+        ranges = P.shard_ranges(frames, gop, world)
+        first, end = ranges[rank] if rank < len(ranges) else (frames, frames)
+        shard = P.StreamShard(w, h, first, end, gop, QP, device=dev, slices=a.slices, **kw) if end > first else None
+        enc = shard.enc if shard else None
+        if enc:
+            enc.generate_synth(0, end - first, t0=first, seed=1)
+    else:
+        enc = P.ClipEncoder(w, h, frames, gop=gop, qp=QP, speed=0, device=dev, slices=a.slices, **kw)
+        enc.generate_synth(0, frames, t0=rank * frames, seed=1)   # every rank its own clip (weak scaling)
 
     def barrier():
         if dist is not None:
@@ -134,48 +237,111 @@ def main():
         if on_gpu:
             torch.cuda.synchronize()
 
+    reencoded = 0
+
+    def one_step(profile):
+        nonlocal reencoded
+        if not stream_mode:
+            return enc.encode(profile=profile)
+        st = shard.first_pass() if shard else None
+        # the exact mv_clusters state goes down the ranks: rank r settles once rank r-1 is final (8 bytes per boundary)
+        state = torch.zeros(2, dtype=torch.int32, device=tdev)
+        for r in range(world):
+            if r == rank and shard:
+                exact = shard.settle((int(state[0]), int(state[1])))
+                state = torch.tensor(exact, dtype=torch.int32, device=tdev)
+            dist.broadcast(state, src=r)
+        if shard:
+            reencoded = shard.reencoded
+            return shard.bytes(), [len(f) for f in shard.frames], st
+        return b"", [], None
+
     for _ in range(a.warmup):
-        out, sizes, st = enc.encode()
+        out, sizes, st = one_step(False)
     barrier()
     t0 = time.time()
     mb_ms = splice_ms = 0.0
     launches = 0
     for _ in range(a.steps):
-        out, sizes, st = enc.encode(profile=True)     # HIP events on the encoder's own stream, read after the step
-        mb_ms += st.mb_kernel_ms
-        splice_ms += st.splice_kernel_ms
-        launches += st.kernel_launches
+        out, sizes, st = one_step(True)     # HIP events on the encoder's own stream, read after the step
+        if st is not None:
+            mb_ms += st.mb_kernel_ms
+            splice_ms += st.splice_kernel_ms
+            launches += st.kernel_launches
     barrier()
     dt = time.time() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     per_rank = None
-    if dist is not None and not on_gpu:         # test hook: which stream did every rank produce?
-        import hashlib
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, hashlib.md5(out).hexdigest())
+    stream_md5 = None
+    if dist is not None and (not on_gpu or stream_mode):
+        # test hook / stream mode: which bytes did every rank produce?  (a few MB of coded data; outside the timed region)
+        per = [None] * world
+        dist.all_gather_object(per, out if stream_mode else hashlib.md5(out).hexdigest())
+        if stream_mode:
+            stream_md5 = hashlib.md5(b"".join(per)).hexdigest()
+            per_rank = [hashlib.md5(p).hexdigest() for p in per]
+            ree = [None] * world
+            dist.all_gather_object(ree, reencoded)
+            reencoded = ree
+        else:
+            per_rank = per
 
     if rank == 0:
-        total_mb = world * a.steps * frames * nmb
+        total_frames = a.steps * frames * (1 if stream_mode else world)
+        total_mb = total_frames * nmb
         value = total_mb / dt
-        # useful algorithmic bytes of the clip (frames that were encoded again after a mis-speculation count once)
-        alg_bytes = a.steps * nmb * sum((BYTES_P if (f % GOP) else BYTES_I) for f in range(frames))
-        achieved = alg_bytes / (mb_ms * 1e-3) / 1e9 if mb_ms > 0 else 0.0
+        # useful algorithmic bytes of this rank's frames (frames that were encoded again after a mis-speculation count once)
+        nloc = len(sizes)
+        base = (ranges[0][0] if stream_mode else 0)
+        rd = a.steps * nmb * sum((READ_P if ((base + f) % gop) else READ_I) for f in range(nloc))
+        wr = a.steps * nmb * nloc * WRITE
+        ach_r = rd / (mb_ms * 1e-3) / 1e9 if mb_ms > 0 else 0.0
+        ach_rw = (rd + wr) / (mb_ms * 1e-3) / 1e9 if mb_ms > 0 else 0.0
+        traffic, traffic_src = _pmc_traffic()
         line = {
             "metric": "1080p macroblocks/sec", "value": value, "unit": "macroblocks/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "strong" if stream_mode else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "synthetic %dx%d YUV420 %d frames IPPP GOP %d QP %d on 1xMI355X per rank (BASELINE configs[2])" % (w, h, frames, GOP, QP),
-                       "frames_per_step": frames, "frames_in_flight": st.chains, "fps": world * a.steps * frames / dt,
-                       "coded_bytes_per_step": len(out), "relaunches_per_step": st.reencoded_gops},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": _pmc_traffic(), "kernel": "h264e_mb_kernel", "launches": launches, "avg_launch_ms": mb_ms / max(launches, 1),
-                         "bytes_per_launch": alg_bytes / max(launches, 1), "splice_kernel_ms_total": splice_ms},
+            "config": {"workload": "synthetic %dx%d YUV420 %d frames IPPP GOP %d QP %d, %s (BASELINE configs[2])" %
+                                   (w, h, frames, gop, QP, "ONE stream GOP-sharded over the ranks" if stream_mode else "one clip per rank on 1xMI355X each"),
+                       "frames_per_step": frames, "frames_in_flight": st.chains if st is not None else None, "fps": total_frames / dt,
+                       "coded_bytes_per_step": len(out), "relaunches_per_step": (st.reencoded_gops if st is not None else None),
+                       "slices_per_frame": max(a.slices, 1), "shard": a.shard},
+            # achieved = algorithmic READ bytes (755.2 B/MB at GOP 30) / kernel time; read+write beside it
+            "roofline": {"bound": "hbm", "achieved": ach_r, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_r / HBM_PEAK_GBS,
+                         "achieved_read_write": ach_rw, "frac_read_write": ach_rw / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "h264e_mb_kernel", "launches": launches,
+                         "avg_launch_ms": mb_ms / max(launches, 1), "bytes_per_launch": rd / max(launches, 1),
+                         "bytes_per_launch_read_write": (rd + wr) / max(launches, 1), "splice_kernel_ms_total": splice_ms},
         }
+        ic, ic_src = _issue_counters()
+        if ic:
+            # what actually bounds this kernel: vector-instruction issue.  A wave64 VALU instruction occupies its SIMD for 4 cycles of
+            # the counters' clock domain (MI355X_MICROARCH.md: one wave alone issues at most one per 4); 1024 SIMDs.
+            line["issue_roofline"] = dict(ic, source=ic_src)
         if per_rank is not None:
             line["config"]["per_rank_md5"] = per_rank
+        if stream_mode:
+            line["config"]["stream_md5"] = stream_md5
+            line["config"]["frames_encoded_again_per_rank"] = reencoded
+            g = _golden_md5(w, h, frames, gop, QP) if not a.slices else None
+            line["config"]["parity_full_stream"] = (stream_md5 == g) if g else None
+        elif world == 1:
+            g = _golden_md5(w, h, frames, gop, QP) if not a.slices else None
+            line["config"]["parity_full_stream"] = (hashlib.md5(out).hexdigest() == g) if g else None
+            line["config"]["stream_md5"] = hashlib.md5(out).hexdigest()
+        if world == 1 and on_gpu and not a.no_extras and (w, h) == (W, H):
+            try:
+                line["dropin_api"] = {"fps": dropin_api_fps(P), "unit": "frames/s", "note": "1080p through H264E_encode, frame by frame (upload + one launch + result per call)"}
+            except Exception as e:
+                line["dropin_api"] = {"fps": None, "note": "failed: %r" % (e,)}
+            try:
+                line["e2e"] = e2e_pass(P, enc, frames, w, h)
+            except Exception as e:
+                line["e2e"] = {"fps": None, "note": "failed: %r" % (e,)}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 cb, ref_bytes = cpu_baseline()
@@ -186,7 +352,11 @@ def main():
             except Exception as e:  # the baseline is informational: never lose the GPU line over it
                 line["cpu_baseline"] = {"value": None, "unit": "macroblocks/s", "cores": 1, "kind": "reference", "sample": "failed: %r" % (e,)}
         print(json.dumps(line))
-    enc.close()
+    if stream_mode:
+        if shard:
+            shard.close()
+    else:
+        enc.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -7,3 +7,4 @@ the HIP library has not been built, and encoder creation fails when no HIP devic
 from .binding import (  # noqa: F401
     CreateParam, RunParam, IoYuv, Encoder, ClipEncoder, ClipParam, ClipStats, load, lib_path, build, H264EError,
 )
+from .shard import StreamShard, shard_ranges  # noqa: F401

@@ -41,7 +41,7 @@ class IoYuv(C.Structure):  # h264-lab.h:231-237: 40 bytes
 
 class ClipParam(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("width", "height", "gop", "qp", "speed", "vbv_size_bytes", "device", "max_chains",
-                                       "first_idr_pic_id_state")] + [("mv_clusters_in", C.c_int32 * 2), ("slices", C.c_int), ("kbps", C.c_int), ("resident_frames", C.c_int)]
+                                       "first_idr_pic_id_state")] + [("mv_clusters_in", C.c_int32 * 2), ("slices", C.c_int), ("kbps", C.c_int), ("resident_frames", C.c_int), ("keep_records", C.c_int)]
 
 
 class ClipStats(C.Structure):
@@ -89,6 +89,8 @@ def load(path=None):
     L.H264E_clip_read_recon.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.H264E_clip_set_ssd_output.argtypes = [C.c_void_p, C.c_void_p]
     L.H264E_clip_set_ssd_output.restype = None
+    L.H264E_clip_revalidate.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.H264E_clip_restart.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
     L.H264E_clip_close.argtypes = [C.c_void_p]
     L.H264E_clip_close.restype = None
     L.h264e_hip_device_count.restype = C.c_int
@@ -156,10 +158,10 @@ class ClipEncoder:
     """Whole-clip streaming encode on one GPU (H264E_clip_* extension): consecutive frames as a temporal wavefront."""
 
     def __init__(self, width, height, nframes, gop=30, qp=26, speed=0, device=0, max_chains=0, lib=None,
-                 clusters_in=(0, 0), idr_state=0, slices=0, kbps=0, resident=0):
+                 clusters_in=(0, 0), idr_state=0, slices=0, kbps=0, resident=0, keep_records=0):
         self.L = load(lib)
         self.w, self.h, self.n = width, height, nframes
-        self.par = ClipParam(width, height, gop, qp, speed, 100000 // 8, device, max_chains, idr_state, (C.c_int32 * 2)(*clusters_in), slices, kbps, resident)
+        self.par = ClipParam(width, height, gop, qp, speed, 100000 // 8, device, max_chains, idr_state, (C.c_int32 * 2)(*clusters_in), slices, kbps, resident, keep_records)
         self.c = C.c_void_p()
         if self.L.H264E_clip_open(C.byref(self.c), C.byref(self.par), nframes):
             raise _err(self.L, "H264E_clip_open")
@@ -186,6 +188,18 @@ class ClipEncoder:
         if self.L.H264E_clip_encode(self.c, out.ctypes.data, cap, C.byref(nb), sizes, int(profile), C.byref(st)):
             raise _err(self.L, "H264E_clip_encode")
         return out[: nb.value].tobytes(), list(sizes)[: st.frames], st
+
+    def revalidate(self, exact_in):
+        """(restart_frame or -1, restart_state, end_state) for the exact mv_clusters state in front of this shard"""
+        rf = C.c_int()
+        rs, es = (C.c_int32 * 2)(), (C.c_int32 * 2)()
+        if self.L.H264E_clip_revalidate(self.c, (C.c_int32 * 2)(*exact_in), C.byref(rf), rs, es):
+            raise _err(self.L, "H264E_clip_revalidate")
+        return rf.value, (rs[0], rs[1]), (es[0], es[1])
+
+    def restart(self, frame, state):
+        if self.L.H264E_clip_restart(self.c, frame, (C.c_int32 * 2)(*state)):
+            raise _err(self.L, "H264E_clip_restart")
 
     def read_recon(self, frame):
         cw, ch = (self.w + 15) // 16 * 16, (self.h + 15) // 16 * 16

@@ -16,7 +16,8 @@
  *
  * Extras (new option names, also argv-consuming): --device N; --clip 1 streams the file through the clip encoder (H264E_clip_*:
  * consecutive frames as a temporal wavefront on the GPU, same bitstream, bounded host memory whatever the file size; --kbps,
- * --threads, --psnr, --stats work there too); --chains N bounds the frames in flight per launch.
+ * --threads, --psnr, --stats work there too); --chains N bounds the frames in flight per launch; --gpus N cuts the file into N
+ * GOP-aligned blocks, one clip encoder per block and GPU, with the mv_clusters state handed over and validated at every boundary.
  */
 #define _FILE_OFFSET_BITS 64
 #include <math.h>
@@ -29,7 +30,7 @@ static struct
 {
     char input_file[1024], output_file[1024], recon_file[1024];
     int have_input, have_output;
-    int gop, qp, kbps, max_frames, speed, stats, psnr, device, clip, chains, threads;
+    int gop, qp, kbps, max_frames, speed, stats, psnr, device, clip, chains, threads, gpus;
 } cmd;
 
 static int starts(const char *pattern, const char *p) { return !strncmp(pattern, p, strlen(pattern)); }
@@ -51,6 +52,7 @@ static void parse_long(const char *p, const char *val)
     else if (starts("device", p)) cmd.device = atoi(v);
     else if (starts("clip", p)) cmd.clip = atoi(v);
     else if (starts("chains", p)) cmd.chains = atoi(v);
+    else if (starts("gpus", p)) cmd.gpus = atoi(v);
     else printf("ERROR: Unknown option %s\n", p);
 }
 
@@ -85,7 +87,7 @@ static int read_cmdline(int argc, char **argv)
                "    4sif cif sif pal ntsc d1 16cif 16sif 720p 4SVGA 4XGA 16VGA 16VGA\n"
                "Options (every --option takes a value):\n"
                "    --input,  -i <f>  --output, -o <f>  --gop <n>  --qp <n>  --kbps <n>  --maxframes <n>\n"
-               "    --speed <n>  --threads <n>  --stats x  --psnr x  --device <n>  --clip 1  --chains <n>\n");
+               "    --speed <n>  --threads <n>  --stats x  --psnr x  --device <n>  --clip 1  --chains <n>  --gpus <n>\n");
         return 0;
     }
     return 1;
@@ -169,11 +171,12 @@ typedef struct
 {
     FILE *fin;
     size_t fsz;
-    int nframes, chunk;                 /* frames in the file region, frames per staging buffer */
+    int nframes, chunk;                 /* frames still to read from the current file position, frames per staging buffer */
+    int base;                           /* stream index (within the shard) of the first of them */
     uint8_t *buf[2];
     int have[2];                        /* frames waiting in buf[k] (0 = free) */
     int first[2];                       /* their first frame index */
-    int eof, error;
+    int eof, error, quit;
     pthread_mutex_t mu;
     pthread_cond_t cv;
 } feeder_t;
@@ -186,11 +189,12 @@ static void *feeder_thread(void *arg)
     {
         const int n = f->nframes - next < f->chunk ? f->nframes - next : f->chunk;
         pthread_mutex_lock(&f->mu);
-        while (f->have[k]) pthread_cond_wait(&f->cv, &f->mu);
+        while (f->have[k] && !f->quit) pthread_cond_wait(&f->cv, &f->mu);
         pthread_mutex_unlock(&f->mu);
+        if (f->quit) break;
         if (fread(f->buf[k], f->fsz, (size_t)n, f->fin) != (size_t)n) { f->error = 1; break; }
         pthread_mutex_lock(&f->mu);
-        f->first[k] = next; f->have[k] = n;
+        f->first[k] = f->base + next; f->have[k] = n;
         pthread_cond_broadcast(&f->cv);
         pthread_mutex_unlock(&f->mu);
         next += n; k ^= 1;
@@ -232,99 +236,232 @@ static void pump(void *token)
     }
 }
 
-static int run_clip_mode(FILE *fin, FILE *fout, int w, int h)
+/* one shard = a GOP-aligned block of the file on one GPU (the whole file without --gpus) */
+typedef struct
 {
-    const size_t fsz = (size_t)w*h*3/2;
+    int device, file_first, nframes, w, h;
+    FILE *fout;                         /* write the stream as it is produced (single shard), or NULL: collect it in `mem` */
+    uint8_t *mem; size_t mem_len, mem_cap;
+    size_t *foff;                       /* [nframes + 1] byte offset of every frame in the shard's stream */
+    int *fsize;                         /* [nframes] */
+    uint64_t *ssd;                      /* [nframes][3] or NULL */
+    H264E_clip_t *clip;
+    H264E_clip_param_t par;
+    uint8_t *stage[2], *out;
+    size_t out_cap;
+    int chunk, chains, rounds, relaunches, reencoded, rc;
+    double enc_ms;
+    pthread_t thread;
+} shard_t;
+
+static int shard_open(shard_t *s)
+{
+    const size_t fsz = (size_t)s->w*s->h*3/2;
     /* budgets (host: two staging buffers + the output buffer; HBM: the input ring); the environment overrides exist for tests that
      * want the ring to wrap and the output buffer to fill on tiny clips */
     const size_t stage_bytes = getenv("H264E_APP_STAGE_KB") ? (size_t)atol(getenv("H264E_APP_STAGE_KB")) << 10 : (size_t)384 << 20;
     const size_t ring_bytes = getenv("H264E_APP_RING_KB") ? (size_t)atol(getenv("H264E_APP_RING_KB")) << 10 : (size_t)6 << 30;
     const size_t out_cap = getenv("H264E_APP_OUT_KB") ? (size_t)atol(getenv("H264E_APP_OUT_KB")) << 10 : (size_t)64 << 20;
-    H264E_clip_param_t par;
-    H264E_clip_stats_t st;
-    H264E_clip_t *clip = NULL;
+    const int n = s->nframes;
+    s->chunk = (int)(stage_bytes/fsz); if (s->chunk < 1) s->chunk = 1; if (s->chunk > n) s->chunk = n;
+    s->par.resident_frames = (int)(ring_bytes/fsz);
+    if (s->par.resident_frames < 4*s->chunk) s->par.resident_frames = 4*s->chunk;
+    if (s->par.resident_frames > n) s->par.resident_frames = n;
+    s->out_cap = out_cap > 2*fsz + (1 << 16) ? out_cap : 2*fsz + (1 << 16);
+    s->stage[0] = (uint8_t *)H264E_clip_host_alloc(fsz*(size_t)s->chunk);
+    s->stage[1] = (uint8_t *)H264E_clip_host_alloc(fsz*(size_t)s->chunk);
+    s->out = (uint8_t *)malloc(s->out_cap);
+    s->fsize = (int *)calloc((size_t)n, sizeof(int));
+    s->foff = (size_t *)calloc((size_t)n + 1, sizeof(size_t));
+    if (cmd.psnr) s->ssd = (uint64_t *)calloc(3*(size_t)n, sizeof(uint64_t));
+    if (!s->stage[0] || !s->stage[1] || !s->out || !s->fsize || !s->foff || (cmd.psnr && !s->ssd)) { printf("ERROR: not enough memory\n"); return 1; }
+    if (H264E_clip_open(&s->clip, &s->par, n)) { printf("ERROR: %s\n", H264E_last_error()); return 1; }
+    return 0;
+}
+
+static void shard_close(shard_t *s)
+{
+    if (s->clip) { (void)H264E_clip_upload_wait(s->clip); H264E_clip_close(s->clip); }
+    H264E_clip_host_free(s->stage[0]); H264E_clip_host_free(s->stage[1]);
+    free(s->out); free(s->fsize); free(s->foff); free(s->ssd); free(s->mem);
+}
+
+/* (re)encode frames [from, nframes) of the shard: reader thread -> staging buffers -> HBM ring -> clip encoder -> output */
+static int shard_encode_from(shard_t *s, int from)
+{
+    const size_t fsz = (size_t)s->w*s->h*3/2;
     feeder_t fd;
     pump_t pp;
     pthread_t th;
-    long long total;
-    int n, i, *sizes, done = 0, rc = 1, rounds = 0, relaunches = 0;
-    uint8_t *out;
-    uint64_t *ssd = NULL;
-    double enc_ms = 0;
-    fseeko(fin, 0, SEEK_END);
-    total = (long long)ftello(fin);
-    fseeko(fin, 0, SEEK_SET);
-    n = (int)((unsigned long long)total/fsz);
-    if (n <= 0) return 0;
-    memset(&par, 0, sizeof(par));
-    par.width = w; par.height = h; par.gop = cmd.gop; par.qp = cmd.qp; par.speed = cmd.speed; par.vbv_size_bytes = 100000/8;
-    par.device = cmd.device < 0 ? 0 : cmd.device; par.max_chains = cmd.chains; par.slices = cmd.threads; par.kbps = cmd.kbps;
+    H264E_clip_stats_t st;
+    uint64_t *ssd_tmp = s->ssd ? (uint64_t *)malloc(sizeof(uint64_t)*3*(size_t)s->nframes) : NULL;
+    int *sizes = (int *)malloc(sizeof(int)*(size_t)s->nframes);
+    int done = from, rc = 1, i;
+    FILE *fin = fopen(cmd.input_file, "rb");
+    if (!fin || !sizes || (s->ssd && !ssd_tmp)) { printf("ERROR: cant open input file %s\n", cmd.input_file); return 1; }
+    fseeko(fin, (off_t)fsz*(off_t)(s->file_first + from), SEEK_SET);
     memset(&fd, 0, sizeof(fd));
-    fd.fin = fin; fd.fsz = fsz; fd.nframes = n;
-    fd.chunk = (int)(stage_bytes/fsz); if (fd.chunk < 1) fd.chunk = 1; if (fd.chunk > n) fd.chunk = n;
-    par.resident_frames = (int)(ring_bytes/fsz);
-    if (par.resident_frames < 4*fd.chunk) par.resident_frames = 4*fd.chunk;
-    if (par.resident_frames > n) par.resident_frames = n;
+    fd.fin = fin; fd.fsz = fsz; fd.nframes = s->nframes - from; fd.base = from; fd.chunk = s->chunk;
+    fd.buf[0] = s->stage[0]; fd.buf[1] = s->stage[1];
     pthread_mutex_init(&fd.mu, NULL); pthread_cond_init(&fd.cv, NULL);
-    fd.buf[0] = (uint8_t *)H264E_clip_host_alloc(fsz*(size_t)fd.chunk);
-    fd.buf[1] = (uint8_t *)H264E_clip_host_alloc(fsz*(size_t)fd.chunk);
-    out = (uint8_t *)malloc(out_cap > 2*fsz + (1 << 16) ? out_cap : 2*fsz + (1 << 16));
-    sizes = (int *)malloc(sizeof(int)*(size_t)n);
-    if (cmd.psnr) ssd = (uint64_t *)malloc(sizeof(uint64_t)*3*(size_t)n);
-    if (!fd.buf[0] || !fd.buf[1] || !out || !sizes || (cmd.psnr && !ssd)) { printf("ERROR: not enough memory\n"); return 1; }
-    if (H264E_clip_open(&clip, &par, n)) { printf("ERROR: %s\n", H264E_last_error()); return 1; }
-    pp.f = &fd; pp.clip = clip; pp.resident = par.resident_frames; pp.inflight = -1; pp.next_buf = 0;
-    H264E_clip_set_idle_hook(clip, pump, &pp);
-    if (pthread_create(&th, NULL, feeder_thread, &fd)) { printf("ERROR: cannot start the reader thread\n"); return 1; }
-    while (done < n)
+    pp.f = &fd; pp.clip = s->clip; pp.resident = s->par.resident_frames; pp.inflight = -1; pp.next_buf = 0;
+    H264E_clip_set_idle_hook(s->clip, pump, &pp);
+    s->mem_len = s->foff[from];
+    if (pthread_create(&th, NULL, feeder_thread, &fd)) { printf("ERROR: cannot start the reader thread\n"); fclose(fin); return 1; }
+    while (done < s->nframes)
     {
         int next_frame, avail;
-        size_t nb = 0;
+        size_t nb = 0, pos = 0;
         pump(&pp);
-        H264E_clip_position(clip, &next_frame, &avail);
+        H264E_clip_position(s->clip, &next_frame, &avail);
         if (avail <= next_frame)
         {
             if (fd.error) { printf("ERROR: short read\n"); goto out; }
             usleep(200);
             continue;
         }
-        if (ssd) H264E_clip_set_ssd_output(clip, ssd);
-        if (H264E_clip_encode(clip, out, out_cap > 2*fsz + (1 << 16) ? out_cap : 2*fsz + (1 << 16), &nb, sizes, 0, &st)) { printf("ERROR: %s\n", H264E_last_error()); goto out; }
-        if (nb && !fwrite(out, nb, 1, fout)) { printf("ERROR writing output file\n"); goto out; }
+        if (ssd_tmp) H264E_clip_set_ssd_output(s->clip, ssd_tmp);
+        if (H264E_clip_encode(s->clip, s->out, s->out_cap, &nb, sizes, 0, &st)) { printf("ERROR: %s\n", H264E_last_error()); goto out; }
+        if (s->fout) { if (nb && !fwrite(s->out, nb, 1, s->fout)) { printf("ERROR writing output file\n"); goto out; } }
+        else
+        {
+            if (s->mem_len + nb > s->mem_cap)
+            {
+                const size_t ncap = (s->mem_len + nb)*2 + (1 << 20);
+                uint8_t *t = (uint8_t *)realloc(s->mem, ncap);
+                if (!t) { printf("ERROR: not enough memory\n"); goto out; }
+                s->mem = t; s->mem_cap = ncap;
+            }
+            memcpy(s->mem + s->mem_len, s->out, nb);
+        }
         for (i = 0; i < st.frames; i++)
         {
-            if (cmd.stats) printf("frame=%d, bytes=%d\n", st.first_frame + i, sizes[i]);
-            if (ssd)
-            {
-                int k, pw = w, ph = h;
-                for (k = 0; k < 3; k++)
-                {
-                    g_psnr.count[k] += pw*ph;
-                    g_psnr.noise[k] += (double)ssd[3*i + k];
-                    if (!k) pw >>= 1, ph >>= 1;
-                }
-                g_psnr.frames++;
-                g_psnr.bytes += sizes[i];
-            }
+            const int f = st.first_frame + i;
+            s->fsize[f] = sizes[i];
+            s->foff[f] = s->mem_len + pos;
+            pos += (size_t)sizes[i];
+            s->foff[f + 1] = s->mem_len + pos;
+            if (ssd_tmp) memcpy(s->ssd + 3*(size_t)f, ssd_tmp + 3*(size_t)i, 3*sizeof(uint64_t));
         }
-        done += st.frames; rounds += st.rounds; relaunches += st.reencoded_gops; enc_ms += st.encode_ms;
+        s->mem_len += nb;
+        done += st.frames; s->rounds += st.rounds; s->relaunches += st.reencoded_gops; s->enc_ms += st.encode_ms; s->chains = st.chains;
     }
     rc = 0;
-    if (cmd.psnr) psnr_print();
-    fprintf(stderr, "clip: %d frames, %d in flight per launch, %d launches (%d after a mis-speculated mv_clusters state), encode %.1f ms, input ring %d frames, staging 2 x %d frames\n",
-            n, st.chains, rounds, relaunches, enc_ms, par.resident_frames, fd.chunk);
 out:
-    /* let the reader finish (it may be blocked on a full buffer) */
     pthread_mutex_lock(&fd.mu);
-    fd.nframes = 0; fd.have[0] = fd.have[1] = 0;
+    fd.quit = 1; fd.have[0] = fd.have[1] = 0;
     pthread_cond_broadcast(&fd.cv);
     pthread_mutex_unlock(&fd.mu);
-    if (rc) pthread_cancel(th);
     pthread_join(th, NULL);
-    (void)H264E_clip_upload_wait(clip);
-    H264E_clip_close(clip);
-    H264E_clip_host_free(fd.buf[0]); H264E_clip_host_free(fd.buf[1]);
-    free(out); free(sizes); free(ssd);
+    (void)H264E_clip_upload_wait(s->clip);
+    H264E_clip_set_idle_hook(s->clip, NULL, NULL);
+    fclose(fin);
+    free(sizes); free(ssd_tmp);
+    return rc;
+}
+
+static void *shard_thread(void *arg)
+{
+    shard_t *s = (shard_t *)arg;
+    s->rc = shard_encode_from(s, 0);
+    return NULL;
+}
+
+/*
+ * --clip 1 [--gpus N]: without --gpus one shard covers the file and writes the stream as it is produced.  With --gpus N the
+ * file is cut into N contiguous GOP-aligned blocks, one clip encoder per block on device k (minih264e_test.c:576-662 is the
+ * loop this replaces).  A block starts from a SPECULATED mv_clusters state; once the block in front of
+ * it is final, its exact end state is handed over (8 bytes) and H264E_clip_revalidate names the GOP from which the block has
+ * to be encoded again, if any; idr_pic_id parity is computed.  The blocks' bytes are written in order at the end.
+ */
+static int run_clip_mode(FILE *fout, int w, int h, long long total)
+{
+    const size_t fsz = (size_t)w*h*3/2;
+    const int n = (int)((unsigned long long)total/fsz), gop = cmd.gop > 0 ? cmd.gop : n;
+    const int ngop = (n + gop - 1)/gop;
+    int nsh = cmd.gpus > 1 ? cmd.gpus : 1, k, g0 = 0, rc = 1, ndev = cmd.gpus > 1 ? H264E_device_count() : 1, f;
+    shard_t *sh;
+    int32_t state[2] = { 0, 0 };
+    if (n <= 0) return 0;
+    if (cmd.kbps) nsh = 1;                  /* rate control state crosses every frame: one shard */
+    if (nsh > ngop) nsh = ngop;
+    if (ndev < 1) ndev = 1;
+    sh = (shard_t *)calloc((size_t)nsh, sizeof(*sh));
+    if (!sh) return 1;
+    for (k = 0; k < nsh; k++)
+    {
+        const int g1 = g0 + (ngop - g0)/(nsh - k);
+        shard_t *s = sh + k;
+        s->w = w; s->h = h;
+        s->file_first = g0*gop; s->nframes = (g1*gop < n ? g1*gop : n) - g0*gop;
+        s->device = cmd.device >= 0 && nsh == 1 ? cmd.device : k % ndev;
+        s->fout = nsh == 1 ? fout : NULL;
+        s->par.width = w; s->par.height = h; s->par.gop = cmd.gop; s->par.qp = cmd.qp; s->par.speed = cmd.speed; s->par.vbv_size_bytes = 100000/8;
+        s->par.device = s->device; s->par.max_chains = cmd.chains; s->par.slices = cmd.threads; s->par.kbps = cmd.kbps;
+        s->par.first_idr_pic_id_state = g0 & 1;         /* idr_pic_id toggles with every key frame (h264-lab.h:6774) */
+        s->par.keep_records = nsh > 1;
+        if (shard_open(s)) goto out;
+        g0 = g1;
+    }
+    if (nsh == 1) sh[0].rc = shard_encode_from(sh, 0);
+    else
+    {
+        for (k = 0; k < nsh; k++) if (pthread_create(&sh[k].thread, NULL, shard_thread, sh + k)) { printf("ERROR: cannot start a shard thread\n"); goto out; }
+        for (k = 0; k < nsh; k++) pthread_join(sh[k].thread, NULL);
+    }
+    for (k = 0; k < nsh; k++) if (sh[k].rc) goto out;
+    /* settle the shards in stream order: exact state in, encode again from the first GOP that consumed different candidates */
+    for (k = 1; k < nsh; k++)
+    {
+        int32_t rs[2], es[2];
+        int rf;
+        if (k == 1 && H264E_clip_revalidate(sh[0].clip, state, &rf, rs, state)) goto out;      /* shard 0 started exact: its end state */
+        for (;;)
+        {
+            if (H264E_clip_revalidate(sh[k].clip, state, &rf, rs, es)) { printf("ERROR: revalidation failed\n"); goto out; }
+            if (rf < 0) break;
+            sh[k].reencoded += sh[k].nframes - rf;
+            if (H264E_clip_restart(sh[k].clip, rf, rs) || shard_encode_from(sh + k, rf)) goto out;
+        }
+        state[0] = es[0]; state[1] = es[1];
+    }
+    for (k = 0; k < nsh && nsh > 1; k++)
+        if (sh[k].mem_len && !fwrite(sh[k].mem, sh[k].mem_len, 1, fout)) { printf("ERROR writing output file\n"); goto out; }
+    for (k = 0, f = 0; k < nsh; k++)
+    {
+        int i;
+        for (i = 0; i < sh[k].nframes; i++, f++)
+        {
+            if (cmd.stats) printf("frame=%d, bytes=%d\n", f, sh[k].fsize[i]);
+            if (sh[k].ssd)
+            {
+                int c, pw = w, ph = h;
+                for (c = 0; c < 3; c++)
+                {
+                    g_psnr.count[c] += pw*ph;
+                    g_psnr.noise[c] += (double)sh[k].ssd[3*(size_t)i + c];
+                    if (!c) pw >>= 1, ph >>= 1;
+                }
+                g_psnr.frames++;
+                g_psnr.bytes += sh[k].fsize[i];
+            }
+        }
+    }
+    if (cmd.psnr) psnr_print();
+    for (k = 0; k < nsh; k++)
+        fprintf(stderr, "clip%s: %d frames%s, %d in flight per launch, %d launches (%d after a mis-speculated mv_clusters state), encode %.1f ms, input ring %d frames, staging 2 x %d frames%s\n",
+                nsh > 1 ? " shard" : "", sh[k].nframes, nsh > 1 ? " on its GPU" : "", sh[k].chains, sh[k].rounds, sh[k].relaunches, sh[k].enc_ms,
+                sh[k].par.resident_frames, sh[k].chunk, sh[k].reencoded ? " -- frames encoded again after the hand-off of the exact state" : "");
+    if (nsh > 1)
+    {
+        int redo = 0;
+        for (k = 0; k < nsh; k++) redo += sh[k].reencoded;
+        fprintf(stderr, "stream of %d frames GOP-sharded over %d clip encoders on %d device(s): %d frames encoded again after state hand-off\n", n, nsh, ndev < nsh ? ndev : nsh, redo);
+    }
+    rc = 0;
+out:
+    for (k = 0; k < nsh; k++) shard_close(sh + k);
+    free(sh);
     return rc;
 }
 
@@ -361,9 +498,13 @@ int main(int argc, char **argv)
     if (error) { printf("H264E_init error = %d\n", error); return 0; }
     printf("sizeof_persist = %d sizeof_scratch = %d\n", sizeof_persist, sizeof_scratch);
 
-    if (cmd.clip)
+    if (cmd.clip || cmd.gpus > 1)
     {
-        int r = run_clip_mode(fin, fout, w, h);
+        long long total;
+        int r;
+        fseeko(fin, 0, SEEK_END);
+        total = (long long)ftello(fin);
+        r = run_clip_mode(fout, w, h, total);
         fclose(fin); fclose(fout);
         return r;
     }

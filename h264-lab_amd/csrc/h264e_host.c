@@ -33,6 +33,7 @@ static int imax(int a, int b) { return a > b ? a : b; }
 
 const char *H264E_last_error(void) { return g_host_err[0] ? g_host_err : h264e_hip_last_error(); }
 void H264E_set_device(int device) { g_device = device; }
+int H264E_device_count(void) { return h264e_hip_device_count(); }
 
 static int pick_device(void)
 {
@@ -803,6 +804,10 @@ struct H264E_clip_tag
     int32_t after[2]; int have_after;       /* predicted state behind that frame */
     int narrow;                             /* reference-window geometry in use (h264e_dev.h) */
     rc_t rcs; int rc_frame, rc_qp;          /* rate control: state, the frame rc_frame_start has run for, its QP */
+    /* keep_records: what every accepted frame consumed, so that a different start state can be validated later (GOP shards) */
+    h264e_hip_mbrec_t **rec_store;          /* [nframes] macroblock records of the accepted encode, or NULL */
+    int32_t (*used_store)[2];               /* [nframes] frame-constant candidates it was given ... */
+    int32_t **permb_store;                  /* [nframes] ... or the per-macroblock trajectory it was given */
     uint64_t *ssd_out;                      /* optional: [3] sums of squared differences input vs reconstruction per encoded frame of a call */
     int32_t *traj;                          /* scratch: walked trajectory [nmb][2] */
     h264e_hip_task_t *tasks;                /* scratch [ring] */
@@ -862,6 +867,13 @@ int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nfram
         free(c->traj); free(c->tasks); free(c->used); free(c);
         return -1;
     }
+    if (par->keep_records)
+    {
+        c->rec_store = (h264e_hip_mbrec_t **)calloc((size_t)nframes, sizeof(*c->rec_store));
+        c->used_store = (int32_t (*)[2])calloc((size_t)nframes, sizeof(int32_t[2]));
+        c->permb_store = (int32_t **)calloc((size_t)nframes, sizeof(*c->permb_store));
+        if (!c->rec_store || !c->used_store || !c->permb_store) { H264E_clip_close(c); return -1; }
+    }
     H264E_clip_rewind(c);
     *out = c;
     return 0;
@@ -871,6 +883,8 @@ void H264E_clip_close(H264E_clip_t *c)
 {
     if (!c) return;
     h264e_hip_pool_destroy(c->pool);
+    if (c->rec_store) { int f; for (f = 0; f < c->nframes; f++) { free(c->rec_store[f]); if (c->permb_store) free(c->permb_store[f]); } }
+    free(c->rec_store); free(c->used_store); free(c->permb_store);
     free(c->first_arr); free(c->traj); free(c->tasks); free(c->used);
     free(c);
 }
@@ -950,6 +964,53 @@ int H264E_clip_read_recon(H264E_clip_t *c, int frame, uint8_t *dst)
 /* [3] sums of squared differences (Y, U, V; input vs reconstruction) per frame encoded by the following H264E_clip_encode calls,
  * computed on the device (encode_app --psnr); NULL switches it off */
 void H264E_clip_set_ssd_output(H264E_clip_t *c, uint64_t *ssd) { if (c) c->ssd_out = ssd; }
+
+/*
+ * GOP sharding of ONE stream: a shard that started from a SPECULATED mv_clusters state is checked once the
+ * exact state in front of its first frame is known (the end state of the shard before it).  Walks every accepted frame from
+ * exact_in with the records kept by keep_records and compares the rounded candidates each macroblock consumed with the exact
+ * ones.  All equal: *restart_frame = -1, the shard's bytes stand, end_state = the exact state behind its last
+ * frame (which becomes the encoder's own state).  Otherwise *restart_frame = first frame of the GOP that holds the first
+ * divergent macroblock and restart_state = the exact state in front of it: everything from there on has to be encoded again
+ * (H264E_clip_restart, then H264E_clip_encode); the frames before it stand.
+ */
+int H264E_clip_revalidate(H264E_clip_t *c, const int32_t exact_in[2], int *restart_frame, int32_t restart_state[2], int32_t end_state[2])
+{
+    const int nslices = c && c->par.slices > 1 ? imin(imin(c->par.slices, H264E_HIP_MAX_SLICES), c->seq.nmby) : 1;
+    int32_t s[2], gop_state[2];
+    int f;
+    if (!c || !c->rec_store || !exact_in || !restart_frame) return -1;
+    s[0] = gop_state[0] = exact_in[0]; s[1] = gop_state[1] = exact_in[1];
+    *restart_frame = -1;
+    for (f = 0; f < c->next; f++)
+    {
+        if (f % c->gop_len == 0) { gop_state[0] = s[0]; gop_state[1] = s[1]; }
+        if (!c->rec_store[f]) return -1;
+        if (clusters_walk(s, c->rec_store[f], c->seq.nmbx, c->seq.nmby, nslices, c->permb_store[f] ? c->permb_store[f] : c->used_store[f], c->permb_store[f] != NULL, NULL) >= 0)
+        {
+            *restart_frame = f - f % c->gop_len;
+            if (restart_state) { restart_state[0] = gop_state[0]; restart_state[1] = gop_state[1]; }
+            return 0;
+        }
+    }
+    if (end_state) { end_state[0] = s[0]; end_state[1] = s[1]; }
+    c->state[0] = s[0]; c->state[1] = s[1];
+    return 0;
+}
+
+/* continue (again) at `frame`, which must start a GOP, with `state` in front of it; the frames behind it are encoded again by the
+ * next H264E_clip_encode calls (their inputs must be resident / uploaded again) */
+int H264E_clip_restart(H264E_clip_t *c, int frame, const int32_t state[2])
+{
+    if (!c || !state || frame < 0 || frame > c->avail || frame % c->gop_len) return -1;
+    c->next = frame;
+    if (c->resident < c->nframes) c->avail = c->pending_avail = frame;      /* a ring: the inputs from here on have to be uploaded again */
+    c->state[0] = state[0]; c->state[1] = state[1];
+    free(c->first_arr); c->first_arr = NULL;
+    c->first_row = 0; c->have_after = 0;
+    c->rc_frame = -1;
+    return 0;
+}
 
 /* diagnostic (stamps build): per-phase cycle sums since the last call */
 int H264E_clip_stamps(H264E_clip_t *c, unsigned long long *dst) { return c ? h264e_hip_stamps_read(c->pool, dst, 1) : -1; }
@@ -1086,6 +1147,17 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
                 pos += w;
                 if (frame_bytes) frame_bytes[f - first] = (int)(pos - start);
                 if (rc_on) rc_frame_end(&c->rcs, nmb, c->par.vbv_size_bytes, desired_frame_bytes, (int)(pos - start), key, r1.all_skipped);
+            }
+            if (c->rec_store)
+            {
+                /* what this accepted frame consumed: records + the candidates it was given (H264E_clip_revalidate) */
+                const size_t rb = sizeof(h264e_hip_mbrec_t)*(size_t)nmb;
+                if (!c->rec_store[f]) c->rec_store[f] = (h264e_hip_mbrec_t *)malloc(rb);
+                if (!c->rec_store[f]) goto done;
+                memcpy(c->rec_store[f], h264e_hip_stream_mbrec(c->pool, slot), rb);
+                c->used_store[f][0] = used[i][0]; c->used_store[f][1] = used[i][1];
+                free(c->permb_store[f]); c->permb_store[f] = NULL;
+                if (per_mb) { c->permb_store[f] = c->first_arr; c->first_arr = NULL; }
             }
             c->state[0] = cc[0]; c->state[1] = cc[1];
             if (i == 0 && c->first_arr) { free(c->first_arr); c->first_arr = NULL; }

@@ -109,6 +109,7 @@ void H264E_close(H264E_persist_t *enc);
 int  H264E_set_slices(H264E_persist_t *enc, int nslices);
 /* Select the HIP device used by subsequent H264E_init calls of this process (default 0 / $H264E_DEVICE). */
 void H264E_set_device(int device);
+int  H264E_device_count(void);
 /* Last device-side error text (empty when none). */
 const char *H264E_last_error(void);
 
@@ -127,6 +128,7 @@ typedef struct
     int slices;                             /* row-band slices per frame: 0 / 1 = one; N = the reference's H264E_MAX_THREADS build with --threads N */
     int kbps;                               /* 0 = constant QP `qp`; > 0 = frame-level rate control as encode_app --kbps (frames then run one per launch) */
     int resident_frames;                    /* input frames kept in HBM (a ring, frame f in slot f % resident_frames); 0 = the whole clip */
+    int keep_records;                       /* keep what every frame consumed, for H264E_clip_revalidate (GOP shards of one stream) */
 } H264E_clip_param_t;
 
 typedef struct
@@ -169,6 +171,12 @@ void H264E_clip_rewind(H264E_clip_t *clip);
 int  H264E_clip_read_recon(H264E_clip_t *clip, int frame, uint8_t *dst);
 /* per encoded frame [3] sums of squared differences input vs reconstruction (Y, U, V), computed on the device: encode_app --psnr */
 void H264E_clip_set_ssd_output(H264E_clip_t *clip, uint64_t *ssd);
+/* GOP shards of ONE stream (one clip encoder per shard / GPU, the shard starting at a key frame with first_idr_pic_id_state =
+ * its GOP index & 1 and a SPECULATED mv_clusters_in): once the exact state in front of the shard is known, revalidate walks the
+ * kept records (keep_records) and either confirms the shard (*restart_frame = -1, end_state = exact state behind it) or names the
+ * GOP from which it has to be encoded again (restart_frame, restart_state); H264E_clip_restart rewinds the encoder to that point. */
+int  H264E_clip_revalidate(H264E_clip_t *clip, const int32_t exact_in[2], int *restart_frame, int32_t restart_state[2], int32_t end_state[2]);
+int  H264E_clip_restart(H264E_clip_t *clip, int frame, const int32_t state[2]);
 void H264E_clip_close(H264E_clip_t *clip);
 /* diagnostic: per-phase cycle sums [32] of a -DH264E_STAMPS kernel build since the last call (zeros in the product) */
 int  H264E_clip_stamps(H264E_clip_t *clip, unsigned long long *dst);

@@ -54,3 +54,28 @@ def test_psnr_line_equals_reference(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         assert [l for l in r.stdout.splitlines() if "YPSNR" in l] == line
         assert (tmp_path / "o.264").read_bytes() == (tmp_path / "r.264").read_bytes()
+
+
+@pytest.mark.parametrize("name,w,h,n,flags,kw,gpus,redo", [
+    ("synth", 176, 144, 40, "--qp 26 --gop 7", dict(gop=7, qp=26), 3, False),
+    ("pan", 352, 288, 12, "--qp 26 --gop 3", dict(gop=3, qp=26), 2, True),
+    ("pan", 352, 288, 12, "--qp 26 --gop 3 --threads 4", dict(gop=3, qp=26, slices=4), 4, False)])
+def test_gpus_option_shards_one_stream(tmp_path, name, w, h, n, flags, kw, gpus, redo):
+    """--gpus N: contiguous GOP blocks of the file on N clip encoders (all on the one emulated device here), started from a
+    speculated mv_clusters state, settled in stream order with the exact state (8 bytes per boundary) -- the concatenation is the
+    oracle's single stream; the fast pan defeats the speculation (frames are encoded again), row-band slices need none"""
+    c = clips.make(name, w, h, n)
+    yuv = tmp_path / ("app_%dx%d.yuv" % (w, h))
+    c.tofile(yuv)
+    fsz = w * h * 3 // 2
+    want, sizes = oracle_lib.encode_clip(c, w, h, **kw)
+    env = dict(os.environ, H264E_APP_STAGE_KB=str(fsz * 2 // 1024 + 1), H264E_APP_RING_KB=str(fsz * 8 // 1024), H264E_APP_OUT_KB="8")
+    out = tmp_path / "o.264"
+    r = subprocess.run([APP, "--input", str(yuv), "--output", str(out), "--clip", "1", "--stats", "x", "--gpus", str(gpus)] + flags.split(), env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert out.read_bytes() == want
+    assert [l for l in r.stdout.splitlines() if l.startswith("frame=")] == ["frame=%d, bytes=%d" % (i, b) for i, b in enumerate(sizes)]
+    last = r.stderr.strip().splitlines()[-1]
+    assert ("GOP-sharded over %d clip encoders" % gpus) in last
+    assert (" 0 frames encoded again" not in last) == redo
