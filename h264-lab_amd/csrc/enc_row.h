@@ -24,6 +24,8 @@ struct ChainG
     GLOBAL_AS h264e_mbrec_t *mbrec;
     GLOBAL_AS uint8_t *arena;
     uint32_t arena_cap;
+    GLOBAL_AS uint8_t *nal_arena;
+    uint32_t nal_cap;
     GLOBAL_AS uint32_t *cursor;
     GLOBAL_AS h264e_frameout_t *fout;
     GLOBAL_AS int *far_reads;
@@ -34,7 +36,7 @@ DEV ChainG chain_view(const h264e_chain_dev_t &C)
     ChainG g;
     g.bottom = (GLOBAL_AS h264e_mbbottom_t *)C.bottom; g.pend = (GLOBAL_AS h264e_mbpend_t *)C.pend; g.progress = (GLOBAL_AS int *)C.progress;
     g.rowbits = (GLOBAL_AS uint32_t *)C.rowbits; g.rowmeta = (GLOBAL_AS h264e_rowmeta_t *)C.rowmeta;
-    g.mbrec = (GLOBAL_AS h264e_mbrec_t *)C.mbrec; g.arena = (GLOBAL_AS uint8_t *)C.arena; g.arena_cap = C.arena_cap;
+    g.mbrec = (GLOBAL_AS h264e_mbrec_t *)C.mbrec; g.arena = (GLOBAL_AS uint8_t *)C.arena; g.arena_cap = C.arena_cap; g.nal_arena = (GLOBAL_AS uint8_t *)C.nal_arena; g.nal_cap = C.nal_cap;
     g.cursor = (GLOBAL_AS uint32_t *)C.cursor; g.fout = (GLOBAL_AS h264e_frameout_t *)C.fout; g.far_reads = (GLOBAL_AS int *)C.far_reads; g.prof = C.prof;
     return g;
 }
@@ -620,9 +622,10 @@ DEV uint32_t nal_escape_copy(GLOBAL_AS uint8_t *dst, uint32_t cap, const GLOBAL_
     return 4u + n + esc;
 }
 
-/* finished frame -> host-mapped memory: every slice as a complete Annex-B NAL (start code + escaped payload), the NALs behind
- * each other at 16-byte aligned offsets, and the macroblock records (16 bytes per lane per pass).  Returns the NAL sizes. */
-DEV void export_frame(const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, uint32_t *nal_bytes /* [H264E_MAX_SLICES], uniform */, uint32_t &total, int &overflow)
+/* finished frame -> every slice as a complete Annex-B NAL (start code + escaped payload) in the slot's device NAL arena, the NALs
+ * behind each other at 16-byte aligned offsets; then NALs (when they fit the host-mapped mirror, which is sized for ordinary
+ * frames: in_device = 0) and macroblock records to host-mapped memory, 16 bytes per lane per pass.  Returns the NAL sizes. */
+DEV void export_frame(const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, uint32_t *nal_bytes /* [H264E_MAX_SLICES], uniform */, uint32_t &total, int &overflow, int &in_device)
 {
     const GLOBAL_AS h264e_frameout_t &F = C.fout[T.frame_slot];
     uint32_t soff = 0, doff = 0;
@@ -633,14 +636,29 @@ DEV void export_frame(const h264e_geom_t &G, const ChainG &C, const h264e_frame_
         if (k < F.nslices)
         {
             const uint32_t n = F.slice_nbytes[k];
-            const uint32_t room = doff < T.host_rbsp_cap ? T.host_rbsp_cap - doff : 0u;
-            const uint32_t w = nal_escape_copy((GLOBAL_AS uint8_t *)T.host_rbsp + doff, room, C.arena + F.offset + soff, n, overflow);
+            const uint32_t room = doff < C.nal_cap ? C.nal_cap - doff : 0u;
+            const uint32_t w = nal_escape_copy(C.nal_arena + doff, room, C.arena + F.offset + soff, n, overflow);
             nal_bytes[k] = w;
             soff += (n + 15u) & ~15u;
             doff += (w + 15u) & ~15u;
         }
     }
     total = doff;
+    in_device = doff > T.host_rbsp_cap;
+    if (!in_device)
+    {
+#ifndef H264E_EMU
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        /* the NAL arena was written by this wave just now */
+#endif
+        wave_sync();
+        const uint32_t nw = (doff + 15u) >> 4;
+        const GLOBAL_AS u32x4 *src = (const GLOBAL_AS u32x4 *)C.nal_arena;
+        GLOBAL_AS u32x4 *dst = (GLOBAL_AS u32x4 *)T.host_rbsp;
+        for (uint32_t base = 0; base < nw; base += 64)
+        {
+            WAVE_FOR(l) { if (base + (uint32_t)l < nw) dst[base + l] = src[base + l]; }
+        }
+    }
     const uint32_t nr = ((uint32_t)G.nmb*(uint32_t)sizeof(h264e_mbrec_t) + 15u) >> 4;
     const GLOBAL_AS u32x4 *rs = (const GLOBAL_AS u32x4 *)(C.mbrec + (size_t)T.frame_slot*G.nmb);
     GLOBAL_AS u32x4 *rd = (GLOBAL_AS u32x4 *)T.host_mbrec;

@@ -110,7 +110,7 @@ typedef struct
     int32_t far_reads;
     int32_t nslices;
     uint32_t slice_nbytes[H264E_MAX_SLICES];
-    int32_t pad[1];
+    int32_t in_device;                  /* the NALs did not fit the host-mapped mirror: fetch them from the slot's device NAL arena */
     int32_t done;                       /* written last: launch id when the job's results are complete, -launch id when it was aborted */
 } h264e_hostdone_t;
 
@@ -125,6 +125,8 @@ typedef struct
     h264e_mbrec_t *mbrec;               /* [frame slots][nmb] */
     uint8_t *arena;
     uint32_t arena_cap;
+    uint8_t *nal_arena;                 /* the frame's slices as finished Annex-B NALs (start code + escapes), 16-byte aligned behind each other */
+    uint32_t nal_cap;
     uint32_t *cursor;
     h264e_frameout_t *fout;             /* [frame slots] */
     int *far_reads;                     /* counter of the frame being encoded (rows add, the finalizer reads and clears) */

@@ -633,7 +633,7 @@ int H264E_init(H264E_persist_t *p, const H264E_create_param_t *par)
     memset(&fresh, 0, sizeof(fresh));
     if (h264e_hip_pool_create(&fresh.pool, pick_device(), par->width, par->height, 1, 1, 1))
         return H264E_STATUS_BAD_ARGUMENT;       /* no device: the HIP path is the only path */
-    fresh.rbsp_cap = (size_t)e->seq.nmb*640 + 2048;
+    fresh.rbsp_cap = (size_t)e->seq.nmb*660 + 8192;
     fresh.rbsp = (uint8_t *)malloc(fresh.rbsp_cap);
     if (!par->const_input_flag) fresh.recon = (uint8_t *)malloc((size_t)e->seq.w*e->seq.h*3/2);
     fresh.owner = e; fresh.owner_bytes = (size_t)sp;
@@ -742,7 +742,14 @@ int H264E_encode(H264E_persist_t *p, H264E_scratch_t *scratch, const H264E_run_p
         e->clusters[0] = run[0][0]; e->clusters[1] = run[0][1];
     }
     {
-        const size_t w = emit_slices(out + out_pos, cap - out_pos, h264e_hip_stream_rbsp(m->pool, 0), &res, opt->nalu_callback, opt->nalu_callback_token);
+        const uint8_t *nals = h264e_hip_stream_rbsp(m->pool, 0);
+        size_t w;
+        if (res.in_device)
+        {
+            if (res.nbytes > m->rbsp_cap || h264e_hip_stream_fetch_nals(m->pool, 0, m->rbsp, res.nbytes)) return H264E_STATUS_BAD_ARGUMENT;
+            nals = m->rbsp;
+        }
+        w = emit_slices(out + out_pos, cap - out_pos, nals, &res, opt->nalu_callback, opt->nalu_callback_token);
         if (!w)
         {
             snprintf(g_host_err, sizeof(g_host_err), "coded frame does not fit the scratch blob");
@@ -810,6 +817,7 @@ struct H264E_clip_tag
     int32_t **permb_store;                  /* [nframes] ... or the per-macroblock trajectory it was given */
     uint64_t *ssd_out;                      /* optional: [3] sums of squared differences input vs reconstruction per encoded frame of a call */
     int32_t *traj;                          /* scratch: walked trajectory [nmb][2] */
+    uint8_t *big; size_t big_cap;           /* scratch: NALs of a frame that did not fit the host mirror */
     h264e_hip_task_t *tasks;                /* scratch [ring] */
     int32_t (*used)[2];                     /* scratch [ring] */
 };
@@ -854,7 +862,9 @@ int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nfram
      * proportionally more (fewer launch boundaries), up to 1024 */
     {
         const int nmb = c->seq.nmb;
-        c->ring = par->max_chains > 0 ? par->max_chains + 1 : imax(97, imin(1025, 97*8160/imax(nmb, 1)));
+        /* large pictures: the ~2000 resident workgroups hold only a few frames (4K 33, 8K 16 at one workgroup per row), so slots
+         * beyond that only cost memory: at most 6500 rows' worth */
+        c->ring = par->max_chains > 0 ? par->max_chains + 1 : imax(imin(97, imax(13, 6500/imax(c->seq.nmby, 1) + 1)), imin(1025, 97*8160/imax(nmb, 1)));
     }
     if (getenv("H264E_RING")) c->ring = atoi(getenv("H264E_RING"));       /* experiments */
     c->ring = imax(2, imin(c->ring, nframes + 1));
@@ -885,7 +895,7 @@ void H264E_clip_close(H264E_clip_t *c)
     h264e_hip_pool_destroy(c->pool);
     if (c->rec_store) { int f; for (f = 0; f < c->nframes; f++) { free(c->rec_store[f]); if (c->permb_store) free(c->permb_store[f]); } }
     free(c->rec_store); free(c->used_store); free(c->permb_store);
-    free(c->first_arr); free(c->traj); free(c->tasks); free(c->used);
+    free(c->first_arr); free(c->traj); free(c->tasks); free(c->used); free(c->big);
     free(c);
 }
 
@@ -955,6 +965,13 @@ int H264E_clip_generate_synth(H264E_clip_t *c, int first, int nframes, int t0, u
 
 /* reconstruction of an already encoded frame (coded size, packed I420), while its picture slot has not been reused: the last
  * ring - 1 frames */
+/* the resident input frames back (measurement helper for bench.py's PCIe-inclusive pass) */
+int H264E_clip_download(H264E_clip_t *c, int first, int nframes, uint8_t *i420)
+{
+    if (!c || c->resident < c->nframes) return -1;
+    return h264e_hip_download_i420(c->pool, first, nframes, i420);
+}
+
 int H264E_clip_read_recon(H264E_clip_t *c, int frame, uint8_t *dst)
 {
     if (!c || !dst || frame < 0 || frame >= c->next || frame < c->next - (c->ring - 1)) return -1;
@@ -1134,6 +1151,13 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
                 /* the frame as the kernel exported it: complete NALs (start codes and emulation prevention done on the device) */
                 const uint8_t *nals = h264e_hip_stream_rbsp(c->pool, slot);
                 size_t start = pos, w = 0, need = (key ? 64 : 0) + r1.nbytes;
+                if (r1.in_device)
+                {
+                    /* larger than the host-mapped mirror (sized for ordinary frames): copy it from the slot's device NAL arena */
+                    if (c->big_cap < r1.nbytes) { free(c->big); c->big_cap = (size_t)r1.nbytes*2; c->big = (uint8_t *)malloc(c->big_cap); }
+                    if (!c->big || h264e_hip_stream_fetch_nals(c->pool, slot, c->big, r1.nbytes)) { c->big_cap = 0; (void)h264e_hip_stream_abort(c->pool); (void)h264e_hip_sync(c->pool); goto done; }
+                    nals = c->big;
+                }
                 if (pos + need > cap)
                 {
                     /* the caller's buffer is full: stop here, the stream continues with this frame in the next call */

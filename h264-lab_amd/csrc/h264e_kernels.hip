@@ -96,8 +96,8 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             uint32_t nal_bytes[H264E_MAX_SLICES], nal_total = 0;
-            int exp_overflow = 0;
-            export_frame(G, C, T, nal_bytes, nal_total, exp_overflow);
+            int exp_overflow = 0, in_device = 0;
+            export_frame(G, C, T, nal_bytes, nal_total, exp_overflow, in_device);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0)
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
                 const GLOBAL_AS h264e_frameout_t &F = C.fout[T.frame_slot];
                 GLOBAL_AS h264e_hostdone_t *hd = (GLOBAL_AS h264e_hostdone_t *)T.host_done;
                 hd->nbytes = nal_total; hd->all_skipped = F.all_skipped;
-                hd->nslices = F.nslices;
+                hd->nslices = F.nslices; hd->in_device = in_device;
 #pragma unroll
                 for (int k = 0; k < H264E_MAX_SLICES; k++) hd->slice_nbytes[k] = nal_bytes[k];
                 hd->clusters_moved = F.clusters_moved; hd->overflow = F.overflow | exp_overflow; hd->far_reads = F.far_reads;
@@ -403,7 +403,11 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     int bad = 0;
     const size_t plane = (size_t)G.W*G.H*3/2;
     const uint32_t arena_cap = (uint32_t)((size_t)slots*((size_t)G.nmb*640 + 1024));
-    p->host_rbsp_cap = (uint32_t)((size_t)G.nmb*640 + 1024);
+    /* host-mapped mirror per slot: sized for ordinary frames (160 B per macroblock; a 1080p key frame at QP 26 needs ~20); a
+     * frame that does not fit stays in the slot's device NAL arena (worst-case size) and is fetched with a copy */
+    const uint32_t nal_cap = (uint32_t)((size_t)G.nmb*660 + 4096);
+    p->host_rbsp_cap = getenv("H264E_HOST_MIRROR_BYTES") ? (uint32_t)atol(getenv("H264E_HOST_MIRROR_BYTES")) : (uint32_t)((size_t)G.nmb*160 + 65536);
+    if (p->host_rbsp_cap > nal_cap) p->host_rbsp_cap = nal_cap;
     /* One device allocation and one host-mapped allocation per pool, carved by a bump pointer: pass 0 sizes them, pass 1
      * hands out the pointers.  (Hundreds of separate small allocations get small page-table fragments; one large block is
      * mapped with large ones, and every macroblock touches about ten of these buffers.) */
@@ -441,6 +445,8 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
             C.mbrec = (h264e_mbrec_t *)carve(sizeof(h264e_mbrec_t)*(size_t)G.nmb*slots, 256);
             C.arena = (uint8_t *)carve(arena_cap, 256);
             C.arena_cap = arena_cap;
+            C.nal_arena = slots == 1 ? (uint8_t *)carve(nal_cap, 256) : 0;
+            C.nal_cap = slots == 1 ? nal_cap : 0;
             C.cursor = (uint32_t *)carve(16, 256);
             C.fout = (h264e_frameout_t *)carve(sizeof(h264e_frameout_t)*(size_t)slots, 256);
             C.prof = (unsigned long long *)carve(sizeof(unsigned long long)*32, 256);
@@ -822,11 +828,11 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         if (T.host_done)
         {
             uint32_t nal_bytes[H264E_MAX_SLICES], nal_total = 0;
-            int exp_overflow = 0;
-            export_frame(G, C, T, nal_bytes, nal_total, exp_overflow);
+            int exp_overflow = 0, in_device = 0;
+            export_frame(G, C, T, nal_bytes, nal_total, exp_overflow, in_device);
             const h264e_frameout_t &F = C.fout[T.frame_slot];
             T.host_done->nbytes = nal_total; T.host_done->all_skipped = F.all_skipped;
-            T.host_done->nslices = F.nslices;
+            T.host_done->nslices = F.nslices; T.host_done->in_device = in_device;
             for (int k = 0; k < H264E_MAX_SLICES; k++) T.host_done->slice_nbytes[k] = nal_bytes[k];
             T.host_done->clusters_moved = F.clusters_moved; T.host_done->overflow = F.overflow | exp_overflow; T.host_done->far_reads = F.far_reads;
             T.host_done->done = T.launch_id;
@@ -894,7 +900,7 @@ extern "C" int h264e_hip_stream_done(h264e_hip_pool_t *p, int slot, h264e_hip_re
     if (res)
     {
         res->nbytes = d->nbytes; res->all_skipped = d->all_skipped; res->clusters_moved = d->clusters_moved; res->overflow = d->overflow; res->far_reads = d->far_reads;
-        res->nslices = d->nslices;
+        res->nslices = d->nslices; res->in_device = d->in_device;
         for (int k = 0; k < H264E_HIP_MAX_SLICES; k++) res->slice_nbytes[k] = d->slice_nbytes[k];
     }
     return 1;
@@ -903,6 +909,33 @@ extern "C" int h264e_hip_stream_done(h264e_hip_pool_t *p, int slot, h264e_hip_re
 extern "C" const uint8_t *h264e_hip_stream_rbsp(h264e_hip_pool_t *p, int slot)
 {
     return (p && slot >= 0 && slot < p->nchains) ? p->host_rbsp[slot] : 0;
+}
+
+/* a frame whose NALs did not fit the host mirror (res.in_device): copy them from the slot's device NAL arena; works while the
+ * launch is still running (copy stream) */
+extern "C" int h264e_hip_stream_fetch_nals(h264e_hip_pool_t *p, int slot, uint8_t *dst, uint32_t nbytes)
+{
+    if (!p || !dst || slot < 0 || slot >= p->nchains || !p->chains_host[slot].nal_arena || nbytes > p->chains_host[slot].nal_cap) FAIL("stream_fetch_nals: bad argument");
+#ifdef H264E_EMU
+    memcpy(dst, p->chains_host[slot].nal_arena, nbytes);
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpyAsync(dst, p->chains_host[slot].nal_arena, nbytes, hipMemcpyDeviceToHost, p->copy_stream));
+    HIPCHK(hipStreamSynchronize(p->copy_stream));
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_download_i420(h264e_hip_pool_t *p, int first, int nframes, uint8_t *host)
+{
+    if (!p || !host || first < 0 || nframes < 0 || first + nframes > p->frames_resident) FAIL("download_i420: bad range");
+#ifdef H264E_EMU
+    memcpy(host, p->clip + p->frame_bytes*(size_t)first, p->frame_bytes*(size_t)nframes);
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpy(host, p->clip + p->frame_bytes*(size_t)first, p->frame_bytes*(size_t)nframes, hipMemcpyDeviceToHost));
+#endif
+    return 0;
 }
 
 extern "C" const h264e_hip_mbrec_t *h264e_hip_stream_mbrec(h264e_hip_pool_t *p, int slot)

@@ -68,6 +68,7 @@ typedef struct
     int clusters_moved;         /* the speculated mv_clusters state is not a fixed point of this frame */
     int overflow;               /* a bit buffer overflowed: the result is invalid */
     int far_reads;              /* reference accesses that left the valid window and took the HBM path (stream mode) */
+    int in_device;              /* the NALs did not fit the host-mapped mirror: h264e_hip_stream_fetch_nals() gets them */
 } h264e_hip_result_t;
 
 typedef struct { int32_t mv0; int8_t type; uint8_t used_cand; uint8_t pad[2]; } h264e_hip_mbrec_t;
@@ -101,6 +102,9 @@ int  h264e_hip_step_flags(h264e_hip_pool_t *pool, int *flags /* [nchains][2] */)
 int  h264e_hip_stream_done(h264e_hip_pool_t *pool, int slot, h264e_hip_result_t *res);
 const uint8_t *h264e_hip_stream_rbsp(h264e_hip_pool_t *pool, int slot);
 const h264e_hip_mbrec_t *h264e_hip_stream_mbrec(h264e_hip_pool_t *pool, int slot);
+int  h264e_hip_stream_fetch_nals(h264e_hip_pool_t *pool, int slot, uint8_t *dst, uint32_t nbytes);
+/* resident input frames back to the host (measurement helper) */
+int  h264e_hip_download_i420(h264e_hip_pool_t *pool, int first, int nframes, uint8_t *host_i420);
 int  h264e_hip_stream_abort(h264e_hip_pool_t *pool);
 int  h264e_hip_busy(h264e_hip_pool_t *pool);
 int  h264e_hip_result(h264e_hip_pool_t *pool, int chain, int slot, h264e_hip_result_t *res);

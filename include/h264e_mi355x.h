@@ -167,6 +167,8 @@ int  H264E_clip_encode(H264E_clip_t *clip, uint8_t *out, size_t cap, size_t *out
                        int profile, H264E_clip_stats_t *stats);
 /* back to frame 0 with the stream state of H264E_clip_open (the uploaded frames stay): encode the clip again */
 void H264E_clip_rewind(H264E_clip_t *clip);
+/* resident input frames back to host memory (whole-clip residency only; bench.py's PCIe-inclusive measurement) */
+int  H264E_clip_download(H264E_clip_t *clip, int first, int nframes, uint8_t *i420);
 /* reconstruction (coded size, packed I420) of one of the last frames encoded (its picture slot must not have been reused) */
 int  H264E_clip_read_recon(H264E_clip_t *clip, int frame, uint8_t *dst);
 /* per encoded frame [3] sums of squared differences input vs reconstruction (Y, U, V), computed on the device: encode_app --psnr */

@@ -156,3 +156,22 @@ def test_nal_escape_pass_on_adversarial_payloads():
         assert L.h264e_hip_selftest_nal_escape(pool, p, len(p), dst, cap, C.byref(n)) == 0
         assert dst.raw[: n.value] == want, (len(p), p[:16])
     L.h264e_hip_pool_destroy(pool)
+
+
+def test_frames_larger_than_the_host_mirror_are_fetched(monkeypatch):
+    """the host-mapped result mirror of a slot is sized for ordinary frames; a frame that does not fit stays in the slot's device
+    NAL arena and is fetched with a copy -- forced here with a 2000-byte mirror, both APIs"""
+    monkeypatch.setenv("H264E_HOST_MIRROR_BYTES", "2000")
+    P = pkg.load_pkg()
+    w, h, n = 176, 144, 5
+    c = clips.make("noise", w, h, n)
+    want, sizes = oracle_lib.encode_clip(c, w, h, gop=3, qp=24, slices=2)
+    assert max(sizes) > 2000
+    e = P.Encoder(w, h, gop=3, qp=24, lib=pkg.EMU_LIB, slices=2)
+    assert b"".join(e.encode(c[t]) for t in range(n)) == want
+    e.close()
+    ce = P.ClipEncoder(w, h, n, gop=3, qp=24, lib=pkg.EMU_LIB, slices=2)
+    ce.upload(c)
+    out, fs, _ = ce.encode()
+    ce.close()
+    assert out == want and fs == sizes

@@ -279,3 +279,21 @@ def test_clip_encoder_resumes_across_calls_and_reads_recon(P):
     rec, cw, ch = o.recon()
     assert np.array_equal(ce.read_recon(n - 1), rec)
     ce.close()
+
+
+def test_frames_larger_than_the_host_mirror_are_fetched(P, monkeypatch):
+    """a frame that does not fit the slot's host-mapped mirror (sized for ordinary frames) is fetched from the device NAL arena:
+    forced with a 4000-byte mirror; QP 10 noise also exceeds the default mirror's 160 bytes per macroblock"""
+    w, h, n = 352, 288, 4
+    c = clips.make("noise", w, h, n)
+    want, sizes = oracle_lib.encode_clip(c, w, h, gop=2, qp=10)
+    assert max(sizes) > 396 * 160 + 65536
+    ce = P.ClipEncoder(w, h, n, gop=2, qp=10)
+    ce.upload(c)
+    out, fs, _ = ce.encode()
+    ce.close()
+    assert out == want and fs == sizes
+    monkeypatch.setenv("H264E_HOST_MIRROR_BYTES", "4000")
+    e = P.Encoder(w, h, gop=2, qp=10)
+    assert b"".join(e.encode(c[t]) for t in range(n)) == want
+    e.close()
