@@ -201,6 +201,19 @@ class ClipEncoder:
         if self.L.H264E_clip_restart(self.c, frame, (C.c_int32 * 2)(*state)):
             raise _err(self.L, "H264E_clip_restart")
 
+    def read_records(self, frame):
+        """per-macroblock (mvx, mvy, type, used_cand) of an encoded frame (keep_records=1)"""
+        nmb = ((self.w + 15) // 16) * ((self.h + 15) // 16)
+        buf = np.empty(nmb * 2, np.int32)
+        self.L.H264E_clip_read_records.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        if self.L.H264E_clip_read_records(self.c, frame, buf.ctypes.data):
+            raise _err(self.L, "H264E_clip_read_records")
+        mv, rest = buf[0::2], buf[1::2]
+        mvx = ((mv & 0xffff) ^ 0x8000) - 0x8000
+        mvy = mv >> 16
+        typ = ((rest & 0xff) ^ 0x80) - 0x80
+        return [(int(mvx[i]), int(mvy[i]), int(typ[i]), int((rest[i] >> 8) & 0xff)) for i in range(nmb)]
+
     def read_recon(self, frame):
         cw, ch = (self.w + 15) // 16 * 16, (self.h + 15) // 16 * 16
         buf = np.empty(cw * ch * 3 // 2, np.uint8)

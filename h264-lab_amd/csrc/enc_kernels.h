@@ -151,6 +151,7 @@ struct RefView
     int *fail;                  /* LDS flag: a dynamic wait of this row gave up (spin bound expired): the row must stop and report */
     const int16_t *slice_row;   /* LDS: first macroblock row of every slice of the frame, slice_row[nslices] = nmby */
     int nslices;
+    unsigned spin_limit;
 };
 
 /* wave-uniform: does the sample rectangle [x0,x1] x [y0,y1] lie inside the window? */
@@ -190,7 +191,7 @@ DEV void rv_wait_row(const RefView &V, int drow, int need)
          * samples behind this wait are not final: flag the row, which stops, poisons its counter and (for an expiry) raises the
          * launch's error flag right after this macroblock (h264e_kernels.hip) -- nothing encoded from them is ever returned */
         if (seen < 0) { if (V.fail) *V.fail = seen; break; }
-        if (++spins > (1u << 24)) { if (V.fail) *V.fail = -1; break; }
+        if (++spins > V.spin_limit) { if (V.fail) *V.fail = -1; break; }
         __builtin_amdgcn_s_sleep(8);
     }
 #else

@@ -186,7 +186,7 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
     /* the input macroblock and the reference window are already in LDS (row_prefetch) */
     m.rv.dep = (const GLOBAL_AS int *)T.dep_progress; m.rv.nmbx = G.nmbx; m.rv.nmby = G.nmby;
     m.rv.P = m.ref[0]; m.rv.win = (const lu8 *)L.win; m.rv.has_win = T.slice_type == 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
-    m.rv.vw = NARROW ? H264E_NARROW_VW : WIN_W; m.rv.vh = NARROW ? H264E_NARROW_VH : WIN_W; m.rv.far = &L.far_reads; m.rv.fail = &L.far_fail; m.rv.slice_row = L.slice_row; m.rv.nslices = T.nslices;
+    m.rv.vw = NARROW ? H264E_NARROW_VW : WIN_W; m.rv.vh = NARROW ? H264E_NARROW_VH : WIN_W; m.rv.far = &L.far_reads; m.rv.fail = &L.far_fail; m.rv.slice_row = L.slice_row; m.rv.nslices = T.nslices; m.rv.spin_limit = G.spin_limit;
     STAMP(L, 1);
 
     BitW bw = L.bw;

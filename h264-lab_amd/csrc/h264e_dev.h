@@ -48,6 +48,8 @@ typedef struct
     int nmbx, nmby, nmb, cropping;
     int lim_x0, lim_y0, lim_x1, lim_y1; /* mv_limit, h264-lab.h:6322-6324 */
     int row_words;                      /* 32-bit words per row bit buffer */
+    unsigned spin_limit;                /* bound of every in-kernel wait (polls with s_sleep between them); expiry = reported failure */
+    int test_stall_row;                 /* fault injection (tests): this macroblock row of job 0 exits without ever publishing; -1 = off */
 } h264e_geom_t;
 
 typedef struct

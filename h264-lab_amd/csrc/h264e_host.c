@@ -864,7 +864,8 @@ int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nfram
         const int nmb = c->seq.nmb;
         /* large pictures: the ~2000 resident workgroups hold only a few frames (4K 33, 8K 16 at one workgroup per row), so slots
          * beyond that only cost memory: at most 6500 rows' worth */
-        c->ring = par->max_chains > 0 ? par->max_chains + 1 : imax(imin(97, imax(13, 6500/imax(c->seq.nmby, 1) + 1)), imin(1025, 97*8160/imax(nmb, 1)));
+        /* (row-band slices: relaunches are rare and every frame offers several wavefronts, twice as many slots pay) */
+        c->ring = par->max_chains > 0 ? par->max_chains + 1 : imax(imin(97, imax(13, (par->slices > 1 ? 13000 : 6500)/imax(c->seq.nmby, 1) + 1)), imin(1025, 97*8160/imax(nmb, 1)));
     }
     if (getenv("H264E_RING")) c->ring = atoi(getenv("H264E_RING"));       /* experiments */
     c->ring = imax(2, imin(c->ring, nframes + 1));
@@ -1012,6 +1013,16 @@ int H264E_clip_revalidate(H264E_clip_t *c, const int32_t exact_in[2], int *resta
     }
     if (end_state) { end_state[0] = s[0]; end_state[1] = s[1]; }
     c->state[0] = s[0]; c->state[1] = s[1];
+    return 0;
+}
+
+/* the kept macroblock records of an accepted frame (keep_records): {mv[0] packed (y << 16) | (x & 0xffff), type -1 skip / 0..3 inter
+ * partitioning / 5 I4x4 / 6 I16x16, consumed-the-cluster-candidates flag} per macroblock -- what a per-macroblock comparison with another
+ * implementation's trace needs (tests) */
+int H264E_clip_read_records(H264E_clip_t *c, int frame, void *dst /* nmb x 8 bytes */)
+{
+    if (!c || !dst || !c->rec_store || frame < 0 || frame >= c->next || !c->rec_store[frame]) return -1;
+    memcpy(dst, c->rec_store[frame], sizeof(h264e_hip_mbrec_t)*(size_t)c->seq.nmb);
     return 0;
 }
 

@@ -32,11 +32,10 @@ extern "C" const char *h264e_hip_last_error(void) { return g_err; }
 
 #ifndef H264E_EMU
 
-#define SPIN_LIMIT (1u << 24)
 
 /* relaxed poll of one progress counter until it reaches `need`.  Returns 0 = reached, -1 = producer failed or the
  * bound expired, -2 = producer was aborted (negative counters are poison left behind by a row that stopped). */
-DEV int poll_progress(const GLOBAL_AS int *flag, int need, int &seen)
+DEV int poll_progress(const GLOBAL_AS int *flag, int need, int &seen, unsigned spin_limit)
 {
     unsigned spins = 0;
     for (;;)
@@ -44,7 +43,7 @@ DEV int poll_progress(const GLOBAL_AS int *flag, int need, int &seen)
         seen = uni(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));     /* uni: the loop control is scalar */
         if (seen >= need) return 0;
         if (seen < 0) return seen;
-        if (++spins > SPIN_LIMIT) return -1;
+        if (++spins > spin_limit) return -1;
         __builtin_amdgcn_s_sleep(8);
     }
 }
@@ -76,7 +75,7 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
     {
         /* ---- finalizer */
         int st = 0, seen = 0;
-        for (int r = G.nmby - 1; r >= 0 && !st; r--) st = poll_progress(C.progress + r, G.nmbx + 1, seen);
+        for (int r = G.nmby - 1; r >= 0 && !st; r--) st = poll_progress(C.progress + r, G.nmbx + 1, seen, G.spin_limit);
         if (st)
         {
             if (threadIdx.x == 0)
@@ -119,6 +118,7 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
 
     /* ---- macroblock row */
     if (row < T.first_row) return;          /* kept from the previous encode of this frame (its counter already says complete) */
+    if (job == 0 && row == G.test_stall_row) return;    /* fault injection: a producer that never publishes (tests/test_gpu_failures.py) */
     row_begin(L, G, C, T, row);
     int seen = 0, seen_dep = 0;
     int row0 = 0, row1 = G.nmby;            /* the slice (row band) this row belongs to */
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
             for (int k = 0; k < ndeps && !st; k++)
             {
                 int sk = 0;
-                st = poll_progress((const GLOBAL_AS int *)T.dep_progress + (int)((deps >> (10*k)) & 1023), need_dep, sk);
+                st = poll_progress((const GLOBAL_AS int *)T.dep_progress + (int)((deps >> (10*k)) & 1023), need_dep, sk, G.spin_limit);
                 lowest = imin(lowest, sk);
             }
             seen_dep = lowest;
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
         /* ... so that their latency overlaps with the wait for the row above */
         if (!st && seen < need)
         {
-            st = poll_progress(C.progress + (row - 1), need, seen);
+            st = poll_progress(C.progress + (row - 1), need, seen, G.spin_limit);
             if (!st) consumer_acquire();
         }
         if (st)
@@ -381,6 +381,10 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     G.lim_x0 = G.lim_y0 = -14*4;                                    /* h264-lab.h:6322-6324, MV_GUARD 14 */
     G.lim_x1 = (G.W - 2)*4; G.lim_y1 = (G.H - 2)*4;
     G.row_words = G.nmbx*(H264E_ROW_BYTES_PER_MB/4);
+    /* knobs for the failure-path tests only: a tiny row bit buffer (overflow), a short spin bound and a row that never publishes */
+    if (getenv("H264E_TEST_ROW_BYTES_PER_MB")) { const int b = atoi(getenv("H264E_TEST_ROW_BYTES_PER_MB"))/4; G.row_words = G.nmbx*(b > 1 ? b : 1); }
+    G.spin_limit = getenv("H264E_TEST_SPIN_LIMIT") ? (unsigned)atol(getenv("H264E_TEST_SPIN_LIMIT")) : (1u << 24);
+    G.test_stall_row = getenv("H264E_TEST_STALL_ROW") ? atoi(getenv("H264E_TEST_STALL_ROW")) : -1;
     p->frame_bytes = (size_t)width*height*3/2;
 #ifndef H264E_EMU
     int ndev = 0;

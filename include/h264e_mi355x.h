@@ -179,6 +179,9 @@ void H264E_clip_set_ssd_output(H264E_clip_t *clip, uint64_t *ssd);
  * GOP from which it has to be encoded again (restart_frame, restart_state); H264E_clip_restart rewinds the encoder to that point. */
 int  H264E_clip_revalidate(H264E_clip_t *clip, const int32_t exact_in[2], int *restart_frame, int32_t restart_state[2], int32_t end_state[2]);
 int  H264E_clip_restart(H264E_clip_t *clip, int frame, const int32_t state[2]);
+/* kept records of an encoded frame (keep_records): per macroblock {int32 mv[0] packed (y << 16) | (x & 0xffff); int8 type: -1 skip,
+ * 0..3 inter partitioning, 5 I4x4, 6 I16x16; uint8 used-cluster-candidates; 2 pad bytes} -- a per-macroblock trace for debugging */
+int  H264E_clip_read_records(H264E_clip_t *clip, int frame, void *dst /* macroblocks x 8 bytes */);
 void H264E_clip_close(H264E_clip_t *clip);
 /* diagnostic: per-phase cycle sums [32] of a -DH264E_STAMPS kernel build since the last call (zeros in the product) */
 int  H264E_clip_stamps(H264E_clip_t *clip, unsigned long long *dst);

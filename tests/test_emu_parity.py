@@ -175,3 +175,41 @@ def test_frames_larger_than_the_host_mirror_are_fetched(monkeypatch):
     out, fs, _ = ce.encode()
     ce.close()
     assert out == want and fs == sizes
+
+
+def test_row_bit_buffer_overflow_is_reported(monkeypatch):
+    """a 16-byte-per-macroblock row bit buffer (test knob) cannot hold QP 10 noise: both APIs fail with an error instead of a
+    truncated stream (the GPU run of this lives in tests/test_gpu_failures.py together with the stuck-producer case)"""
+    monkeypatch.setenv("H264E_TEST_ROW_BYTES_PER_MB", "16")
+    P = pkg.load_pkg()
+    c = clips.make("noise", 176, 144, 2)
+    e = P.Encoder(176, 144, gop=30, qp=10, lib=pkg.EMU_LIB)
+    with pytest.raises(P.H264EError, match="overflow"):
+        e.encode(c[0])
+    e.close()
+    ce = P.ClipEncoder(176, 144, 2, gop=30, qp=10, lib=pkg.EMU_LIB)
+    ce.upload(c)
+    with pytest.raises(P.H264EError, match="overflow"):
+        ce.encode()
+    ce.close()
+
+
+def test_per_macroblock_trace_matches_oracle():
+    """macroblock by macroblock: type and mv[0] of every macroblock against the oracle's per-macroblock trace -- when a stream
+    differs, this names the first macroblock that decided differently instead of "md5 differs" """
+    P = pkg.load_pkg()
+    w, h, n = 176, 144, 4
+    c = clips.make("pan", w, h, n)
+    o = oracle_lib.Encoder(w, h, gop=30, qp=26)
+    ce = P.ClipEncoder(w, h, n, gop=30, qp=26, lib=pkg.EMU_LIB, keep_records=1)
+    ce.upload(c)
+    ce.encode()
+    for t in range(n):
+        o.encode(c[t])
+        want = o.trace()
+        got = ce.read_records(t)
+        for i, ((typ, cbp, mvx, mvy, bitpos), (gx, gy, gt, used)) in enumerate(zip(want, got)):
+            assert gt == typ, "frame %d macroblock %d: type %d, oracle %d" % (t, i, gt, typ)
+            if typ < 5:
+                assert (gx, gy) == (mvx, mvy), "frame %d macroblock %d: mv (%d,%d), oracle (%d,%d)" % (t, i, gx, gy, mvx, mvy)
+    ce.close()

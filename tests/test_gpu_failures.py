@@ -1,0 +1,65 @@
+"""GPU: the failure paths of the persistent kernel -- the only safety nets of a design whose forward progress rests on bounded
+spins (h264e_kernels.hip): a producer that never publishes (spin expiry -> poisoned row counters -> errflag -> the finalizer gives up
+-> an error, not a hang and not a stream), and a row bit buffer that overflows.  Fault injection through test-only environment
+knobs read at pool creation (H264E_TEST_*)."""
+import time
+
+import pytest
+
+import clips
+import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    p = pkg.load_pkg()
+    assert p.load().h264e_hip_device_count() > 0, "no HIP device visible"
+    return p
+
+
+def test_stuck_producer_is_reported_not_hung(P, monkeypatch):
+    """row 3 of the first frame exits without publishing: row 4 spins until the (shortened) bound expires, poisons its counter and
+    raises the launch's error flag; every row below and the finalizer stop on the poison; the API returns an error in bounded time"""
+    monkeypatch.setenv("H264E_TEST_STALL_ROW", "3")
+    monkeypatch.setenv("H264E_TEST_SPIN_LIMIT", "20000")
+    w, h, n = 352, 288, 4
+    c = clips.make("synth", w, h, n)
+    t0 = time.time()
+    ce = P.ClipEncoder(w, h, n, gop=30, qp=26)
+    ce.upload(c)
+    with pytest.raises(P.H264EError) as ei:
+        ce.encode()
+    ce.close()
+    assert time.time() - t0 < 60
+    assert "gave up waiting" in str(ei.value) or "did not complete" in str(ei.value)
+    e = P.Encoder(w, h, gop=30, qp=26)
+    with pytest.raises(P.H264EError):
+        e.encode(c[0])
+    e.close()
+    # and the library is usable afterwards
+    monkeypatch.delenv("H264E_TEST_STALL_ROW")
+    monkeypatch.delenv("H264E_TEST_SPIN_LIMIT")
+    e = P.Encoder(w, h, gop=30, qp=26)
+    assert len(e.encode(c[0])) > 1000
+    e.close()
+
+
+def test_row_bit_buffer_overflow_is_reported(P, monkeypatch):
+    """a 16-byte-per-macroblock row bit buffer cannot hold QP 10 noise: the kernel flags the overflow instead of writing past the
+    buffer, and both APIs fail with the reference-style error instead of returning a truncated stream"""
+    monkeypatch.setenv("H264E_TEST_ROW_BYTES_PER_MB", "16")
+    w, h, n = 176, 144, 2
+    c = clips.make("noise", w, h, n)
+    e = P.Encoder(w, h, gop=30, qp=10)
+    with pytest.raises(P.H264EError) as ei:
+        e.encode(c[0])
+    e.close()
+    assert "overflow" in str(ei.value)
+    ce = P.ClipEncoder(w, h, n, gop=30, qp=10)
+    ce.upload(c)
+    with pytest.raises(P.H264EError) as ei:
+        ce.encode()
+    ce.close()
+    assert "overflow" in str(ei.value)

@@ -297,3 +297,20 @@ def test_frames_larger_than_the_host_mirror_are_fetched(P, monkeypatch):
     e = P.Encoder(w, h, gop=2, qp=10)
     assert b"".join(e.encode(c[t]) for t in range(n)) == want
     e.close()
+
+
+def test_per_macroblock_trace_matches_oracle(P):
+    """type and mv[0] of every macroblock against the oracle's per-macroblock trace (names the first macroblock that differs)"""
+    w, h, n = 352, 288, 4
+    c = clips.make("pan", w, h, n)
+    o = oracle_lib.Encoder(w, h, gop=30, qp=26)
+    ce = P.ClipEncoder(w, h, n, gop=30, qp=26, keep_records=1)
+    ce.upload(c)
+    ce.encode()
+    for t in range(n):
+        o.encode(c[t])
+        for i, ((typ, cbp, mvx, mvy, bitpos), (gx, gy, gt, used)) in enumerate(zip(o.trace(), ce.read_records(t))):
+            assert gt == typ, "frame %d macroblock %d: type %d, oracle %d" % (t, i, gt, typ)
+            if typ < 5:
+                assert (gx, gy) == (mvx, mvy), "frame %d macroblock %d: mv (%d,%d), oracle (%d,%d)" % (t, i, gx, gy, mvx, mvy)
+    ce.close()
