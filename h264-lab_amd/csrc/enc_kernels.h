@@ -39,6 +39,42 @@ DEV mv32 mvround(mv32 a) { return mvmk((mvx(a) + 1) & ~3, (mvy(a) + 1) & ~3); } 
 
 struct qblk_t { int16_t qv[16]; int16_t dq[16]; };
 
+/* What a macroblock row needs of its job's task, BY VALUE in wave-uniform registers: the task itself lives in global memory, and
+ * every hand-off's acquire invalidates the L1, so reading a field where it is used costs an L2 round trip on the critical path
+ * of every macroblock (there are about forty such reads per macroblock). */
+struct RowTask
+{
+    int slice_type, qp, speed, no_deblock, narrow, nslices, frame_slot;
+    const uint8_t *in[3];
+    int in_stride[3];
+    const uint8_t *ref[3];
+    uint8_t *dec[3];
+    const int *dep_progress;
+    mv32 clusters[2];
+    const mv32 *clusters_per_mb;
+};
+#ifdef H264E_EMU
+template <class P> DEV P uniptr(P p) { return p; }
+#else
+template <class P> DEV P uniptr(P p)
+{
+    const unsigned long long v = (unsigned long long)(uintptr_t)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (P)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+#endif
+DEV RowTask rowtask_load(const h264e_frame_task_t &T)
+{
+    RowTask t;
+    t.slice_type = uni(T.slice_type); t.qp = uni(T.qp); t.speed = uni(T.speed); t.no_deblock = uni(T.no_deblock); t.narrow = uni(T.narrow);
+    t.nslices = uni(T.nslices); t.frame_slot = uni(T.frame_slot);
+    for (int c = 0; c < 3; c++) { t.in[c] = uniptr(T.in[c]); t.in_stride[c] = uni(T.in_stride[c]); t.ref[c] = uniptr(T.ref[c]); t.dec[c] = uniptr(T.dec[c]); }
+    t.dep_progress = uniptr(T.dep_progress);
+    t.clusters[0] = (mv32)uni(T.clusters[0]); t.clusters[1] = (mv32)uni(T.clusters[1]);
+    t.clusters_per_mb = uniptr(T.clusters_per_mb);
+    return t;
+}
+
 /* ------------------------------------------------------------------ row bit writer */
 
 struct BitW

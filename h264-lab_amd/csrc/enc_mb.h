@@ -77,7 +77,9 @@ struct RowLds
 struct MbCtx
 {
     const h264e_geom_t *G;
-    const h264e_frame_task_t *T;
+    int speed, slice_type;                          /* of the frame (copied from the row's task: values, no pointer into it) */
+    mv32 clu[2];                                    /* speculated mv_clusters pair of the frame ... */
+    const mv32 *clu_per_mb;                         /* ... or the exact per-macroblock trajectory in HBM (NULL: none) */
     Plane ref[3];
     RefView rv;                                     /* reference luma through the LDS window */
     gu8 *dec[3];
@@ -311,7 +313,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
 
     PTOC(L, 15);
     STAMP(L, 5);
-    if (!(m.T->speed < 9 && in_rect(mv, mv_qlimit(m))))
+    if (!(m.speed < 9 && in_rect(mv, mv_qlimit(m))))
     {
         wave_interp_luma(R, px, py, mv, w, h, dst);
         STAMP(L, 6);
@@ -484,7 +486,7 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
                 return;
             }
         }
-        if (m.T->speed < 1) partition_hints(sad4, prefer);
+        if (m.speed < 1) partition_hints(sad4, prefer);
         mv_best = mvround(mv_skip);
         cand.set(ncand++, mv_best);
         if (!((mvx(mv_skip) | mvy(mv_skip)) & 3))
@@ -505,9 +507,16 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
     if (m.x <= 0) cand.set(ncand++, mvmk(8*4, 0));
     if (m.y <= 0) cand.set(ncand++, mvmk(0, 8*4));
     {
-        const GLOBAL_AS mv32 *clu = m.T->clusters_per_mb ? (const GLOBAL_AS mv32 *)m.T->clusters_per_mb + 2*m.num : (const GLOBAL_AS mv32 *)m.T->clusters;
-        cand.set(ncand++, clu[0]);
-        cand.set(ncand++, clu[1]);
+        /* the speculated mv_clusters pair: frame-constant (registers of the row's task copy) or this macroblock's entry of the
+         * exact trajectory in HBM.  (Values, not a pointer: the frame-constant pair is not in global memory.) */
+        mv32 c0 = m.clu[0], c1 = m.clu[1];
+        if (m.clu_per_mb)
+        {
+            const GLOBAL_AS mv32 *clu = (const GLOBAL_AS mv32 *)m.clu_per_mb + 2*m.num;
+            c0 = clu[0]; c1 = clu[1];
+        }
+        cand.set(ncand++, c0);
+        cand.set(ncand++, c1);
     }
     {   /* H:5198-5218 round to full-pel, drop duplicates */
         int k = 1;
@@ -529,7 +538,7 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
         {
             int c = mv_cost(m, cj, mv_pred16), s4[4];
             sad = wave_sad_ref_q(R, bx + (mvx(cj) >> 2), by + (mvy(cj) >> 2), L.inp, s4);
-            if (m.T->speed < 1) partition_hints(s4, prefer);
+            if (m.speed < 1) partition_hints(s4, prefer);
             if (sad + c < sad_best + cand_cost_best)
             {
                 cand_cost_best = c;
@@ -792,8 +801,8 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
             if (cbpl) cbpl = 15;
             mb_type += m.i16_mode + cbpc*4 + (cbpl ? 12 : 0);
         }
-        if (mb_type >= 5 && m.T->slice_type == 2) mb_type -= 5;
-        if (m.T->slice_type != 2)
+        if (mb_type >= 5 && m.slice_type == 2) mb_type -= 5;
+        if (m.slice_type != 2)
         {
             if (L.coded_any) bw_ue(b, (uint32_t)L.skip_run);
             else L.lead_skips = L.skip_run;             /* the finalizer writes this run: it may extend into earlier rows */

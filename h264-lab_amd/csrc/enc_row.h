@@ -118,7 +118,7 @@ DEV void load_top(RowLds &L, const h264e_geom_t &G, const GLOBAL_AS h264e_mbbott
 }
 
 /* h264-lab.h:5731-5740 + 3536-3562: input macroblock -> LDS, replicating the last valid column / row of cropped pictures */
-DEV void load_input(RowLds &L, const h264e_geom_t &G, const h264e_frame_task_t &T, int mbx, int mby)
+DEV void load_input(RowLds &L, const h264e_geom_t &G, const RowTask &T, int mbx, int mby)
 {
     WAVE_FOR(l)
     {
@@ -144,7 +144,7 @@ DEV void load_input(RowLds &L, const h264e_geom_t &G, const h264e_frame_task_t &
 /* What macroblock (x, row) needs that does not depend on the row above: its input samples and, for P slices, the
  * reference window (the caller has waited for the temporal dependency).  Issued BEFORE the wait for the row above, so
  * the HBM latency of these loads overlaps with that wait. */
-DEV void row_prefetch(RowLds &L, const h264e_geom_t &G, const h264e_frame_task_t &T, int row, int x)
+DEV void row_prefetch(RowLds &L, const h264e_geom_t &G, const RowTask &T, int row, int x)
 {
     load_input(L, G, T, x, row);
     if (T.slice_type == 0)
@@ -159,12 +159,13 @@ DEV void row_prefetch(RowLds &L, const h264e_geom_t &G, const h264e_frame_task_t
 /* row0 / row1: first row and end row of the slice (row band) this row belongs to -- the whole picture for one slice per frame.
  * A slice is encoded like a picture of its own as far as neighbour availability, contexts and deblocking are concerned
  * (h264-lab.h:3605-3622 mb_avail_flag relative to slice.start_mb_num, h264-lab.h:5799-5808 no filtering across its top edge). */
-template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, int row, int x, int row0, int row1)
+template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const RowTask &T, int row, int x, int row0, int row1)
 {
     const bool have_top = row > row0;
     MbCtx m;
     PTIC();
-    m.G = &G; m.T = &T;
+    m.G = &G;
+    m.speed = T.speed; m.slice_type = T.slice_type; m.clu[0] = T.clusters[0]; m.clu[1] = T.clusters[1]; m.clu_per_mb = T.clusters_per_mb;
     for (int c = 0; c < 3; c++)
     {
         m.ref[c].p = (const gu8 *)T.ref[c];

@@ -120,6 +120,9 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
     if (row < T.first_row) return;          /* kept from the previous encode of this frame (its counter already says complete) */
     if (job == 0 && row == G.test_stall_row) return;    /* fault injection: a producer that never publishes (tests/test_gpu_failures.py) */
     row_begin(L, G, C, T, row);
+    const RowTask RT = rowtask_load(T);      /* the task's hot fields, once, in registers */
+    const GLOBAL_AS int *abort_word = (const GLOBAL_AS int *)uniptr(T.abort_word);
+    const int launch_id = uni(T.launch_id);
     int seen = 0, seen_dep = 0;
     int row0 = 0, row1 = G.nmby;            /* the slice (row band) this row belongs to */
     for (int k = 0; k < T.nslices; k++)
@@ -146,10 +149,10 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
     {
         /* consumer: relaxed sc1 polls, then sc1 loads of everything handed over */
         const int need = row > row0 ? imin(x + 2, G.nmbx) : 0;
-        const int need_dep = T.dep_progress ? imin(x + DEP_COLS, G.nmbx) : 0;     /* temporal wavefront: h264e_dev.h */
+        const int need_dep = RT.dep_progress ? imin(x + DEP_COLS, G.nmbx) : 0;     /* temporal wavefront: h264e_dev.h */
         int st = 0;
         /* the abort word lives in host memory (one PCIe read): look at it every 8th macroblock only */
-        if ((x & 7) == 0 && T.abort_word && uni(__hip_atomic_load((const GLOBAL_AS int *)T.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == T.launch_id) st = -2;
+        if ((x & 7) == 0 && abort_word && uni(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == launch_id) st = -2;
         /* temporal dependency first, then the loads that only need it (input, reference window) ... */
         if (!st && seen_dep < need_dep)
         {
@@ -157,13 +160,13 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
             for (int k = 0; k < ndeps && !st; k++)
             {
                 int sk = 0;
-                st = poll_progress((const GLOBAL_AS int *)T.dep_progress + (int)((deps >> (10*k)) & 1023), need_dep, sk, G.spin_limit);
+                st = poll_progress((const GLOBAL_AS int *)RT.dep_progress + (int)((deps >> (10*k)) & 1023), need_dep, sk, G.spin_limit);
                 lowest = imin(lowest, sk);
             }
             seen_dep = lowest;
             if (!st) consumer_acquire();
         }
-        if (!st) row_prefetch(L, G, T, row, x);
+        if (!st) row_prefetch(L, G, RT, row, x);
         /* ... so that their latency overlaps with the wait for the row above */
         if (!st && seen < need)
         {
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
             return;
         }
         STAMP(L, 13);
-        row_step<NARROW>(L, G, C, T, row, x, row0, row1);
+        row_step<NARROW>(L, G, C, RT, row, x, row0, row1);
         {
             /* a far reference read of this macroblock waited in vain (rv_wait_rect): what it encoded is not trustworthy */
             const int ff = uni(L.far_fail);
@@ -824,7 +827,8 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             int row0 = 0, row1 = G.nmby;
             for (int k = 0; k < T.nslices; k++)
                 if (row >= T.slice_row[k] && row < T.slice_row[k + 1]) { row0 = T.slice_row[k]; row1 = T.slice_row[k + 1]; }
-            for (int x = 0; x < G.nmbx; x++) { row_prefetch(*L, G, T, row, x); if (T.narrow) row_step<true>(*L, G, C, T, row, x, row0, row1); else row_step<false>(*L, G, C, T, row, x, row0, row1); }
+            const RowTask RT = rowtask_load(T);
+            for (int x = 0; x < G.nmbx; x++) { row_prefetch(*L, G, RT, row, x); if (T.narrow) row_step<true>(*L, G, C, RT, row, x, row0, row1); else row_step<false>(*L, G, C, RT, row, x, row0, row1); }
             row_end(*L, G, C, row);
             free(L);
         }

@@ -48,12 +48,22 @@ int main()
             else    hipLaunchKernelGGL(pack_kernel<false>, dim3(n/256), dim3(256), 0, 0, din, dout, n, adds[c], shs[c]);
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(o.data(), dout, sizeof(unsigned)*n, hipMemcpyDeviceToHost);
-            int bad = 0, first = -1;
+            int bad = 0, first = -1, shown = 0;
             for (int i = 0; i < n; i++)
             {
                 unsigned want = 0;
                 for (int k = 0; k < 4; k++) want |= (unsigned)clip255((h[4*i + k] + adds[c]) >> shs[c]) << (8*k);
-                if (want != o[i]) { if (first < 0) first = i; bad++; }
+                if (want != o[i])
+                {
+                    if (first < 0) first = i;
+                    bad++;
+                    if (shown < 6)
+                    {
+                        printf("  detail %s_shift%d: inputs+add %d %d %d %d -> got %08x want %08x\n", op ? "opaque" : "plain", shs[c],
+                               h[4*i] + adds[c], h[4*i + 1] + adds[c], h[4*i + 2] + adds[c], h[4*i + 3] + adds[c], o[i], want);
+                        shown++;
+                    }
+                }
             }
             printf("%s_shift%d mismatches=%d first=%d\n", op ? "opaque" : "plain", shs[c], bad, first);
         }
