@@ -468,6 +468,96 @@ DEV void clusters_step(mv32 c[2], mv32 mv)                                  /* h
     if (n >= n0) c[1] = mvmk((63*mvx(c[1]) + mvx(mv) + 32) >> 6, (63*mvy(c[1]) + mvy(mv) + 32) >> 6);
 }
 
+/*
+ * The exact mv_clusters walk of one frame on the device (what h264e_host.c clusters_walk does on the host): from state s, in
+ * raster order -- restarting from s at every slice of a multi-slice frame -- compare the rounded candidates every macroblock
+ * CONSUMED (the frame-constant pair or its entry of the per-macroblock array) with the exact ones, then apply its update
+ * (h264-lab.h:5263-5278).  The chain is serial, but almost no macroblock moves the state: 64 macroblocks per pass, a ballot
+ * finds the next one that moves it or mismatches, everything in front of it is settled at once.  traj (optional) receives the
+ * state in front of every macroblock.  Returns the first mismatching macroblock or -1; s = state behind the frame.
+ */
+DEV int device_clusters_walk(const h264e_geom_t &G, const h264e_frame_task_t &T, const GLOBAL_AS h264e_mbrec_t *rec, mv32 s[2], GLOBAL_AS mv32 *traj)
+{
+    const mv32 s0[2] = { s[0], s[1] };
+    const GLOBAL_AS mv32 *per_mb = (const GLOBAL_AS mv32 *)T.clusters_per_mb;
+    const mv32 u_frame0 = T.clusters[0], u_frame1 = T.clusters[1];
+    int first_bad = -1;
+    for (int band = 0; band < T.nslices; band++)
+    {
+        const int k0 = T.slice_row[band]*G.nmbx, k1 = T.slice_row[band + 1]*G.nmbx;
+        s[0] = s0[0]; s[1] = s0[1];
+        for (int base = k0; base < k1; base += 64)
+        {
+            int start = 0;
+#ifdef H264E_EMU
+            mv32 mine0[64], mine1[64];
+            for (int l = 0; l < 64; l++) { mine0[l] = s[0]; mine1[l] = s[1]; }
+#else
+            mv32 mine0 = s[0], mine1 = s[1];
+#endif
+            for (;;)
+            {
+                const mv32 c0 = s[0], c1 = s[1];
+                const int fb = first_bad;
+                const uint64_t ev = wave_ballot([&](int l) -> int {
+                    const int k = base + l;
+                    if (l < start || k >= k1) return 0;
+                    const mv32 mv0 = rec[k].mv0;
+                    const int type = rec[k].type;
+                    int hit = 0;
+                    if (fb < 0 && rec[k].used_cand)
+                    {
+                        const mv32 u0 = per_mb ? per_mb[2*k] : u_frame0, u1 = per_mb ? per_mb[2*k + 1] : u_frame1;
+                        if (mvround(u0) != mvround(c0) || mvround(u1) != mvround(c1)) hit = 1;
+                    }
+                    if (type < 5)
+                    {
+                        mv32 c[2] = { c0, c1 };
+                        clusters_step(c, mv0);
+                        if (c[0] != c0 || c[1] != c1) hit = 1;
+                    }
+                    return hit;
+                });
+                if (!ev) break;
+                const int e = __builtin_ctzll(ev), ke = base + e;
+                /* macroblock ke: mismatch check first (against the state in front of it), then its update */
+                if (first_bad < 0 && rec[ke].used_cand)
+                {
+                    const mv32 u0 = per_mb ? per_mb[2*ke] : u_frame0, u1 = per_mb ? per_mb[2*ke + 1] : u_frame1;
+                    if (mvround(u0) != mvround(s[0]) || mvround(u1) != mvround(s[1])) first_bad = ke;
+                }
+                if (rec[ke].type < 5) clusters_step(s, rec[ke].mv0);
+                s[0] = (mv32)uni(s[0]); s[1] = (mv32)uni(s[1]); first_bad = uni(first_bad);
+                start = e + 1;
+                WAVE_FOR(l)
+                {
+#ifdef H264E_EMU
+                    if (l >= start) { mine0[l] = s[0]; mine1[l] = s[1]; }
+#else
+                    if (l >= start) { mine0 = s[0]; mine1 = s[1]; }
+#endif
+                }
+                if (start >= 64) break;
+            }
+            if (traj)
+            {
+                WAVE_FOR(l)
+                {
+                    const int k = base + l;
+#ifdef H264E_EMU
+                    if (k < k1) { traj[2*k] = mine0[l]; traj[2*k + 1] = mine1[l]; }
+#else
+                    if (k < k1) { traj[2*k] = mine0; traj[2*k + 1] = mine1; }
+#endif
+                }
+            }
+        }
+    }
+    if (T.nslices > 1) { s[0] = s0[0]; s[1] = s0[1]; }      /* the parent's state never moves in the row-band build (h264-lab.h:6526) */
+    wave_sync();
+    return first_bad;
+}
+
 DEV void finalize_frame(const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, GLOBAL_AS int *stepflags)
 {
     SpliceState s;

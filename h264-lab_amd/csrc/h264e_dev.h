@@ -104,6 +104,19 @@ typedef struct
     int32_t pad[2];
 } h264e_frameout_t;
 
+/* Verdict of a frame's exact mv_clusters walk, done by its finalizer workgroup on the device (stream mode, walk_on_device): the
+ * next frame's finalizer starts its own walk from state_out once `flag` carries the launch id. */
+#define H264E_WALK_OK 1
+#define H264E_WALK_BAD 2                 /* a macroblock consumed rounded candidates that differ from the exact ones: first_bad */
+#define H264E_WALK_VOID 3                /* a frame before it was BAD / aborted: nothing to say about this one */
+typedef struct
+{
+    mv32 state_out[2];                  /* OK: exact state behind the frame; BAD: the walk's end state (prediction for the frames behind) */
+    int32_t status, first_bad;
+    int32_t pad[3];
+    int32_t flag;                       /* written last: launch id */
+} h264e_walkrec_t;
+
 /* per-job result record in HOST (pinned, device-mapped) memory: lets the host consume frames while the launch runs */
 typedef struct
 {
@@ -113,6 +126,8 @@ typedef struct
     int32_t nslices;
     uint32_t slice_nbytes[H264E_MAX_SLICES];
     int32_t in_device;                  /* the NALs did not fit the host-mapped mirror: fetch them from the slot's device NAL arena */
+    int32_t walk_status, first_bad;     /* device-side mv_clusters validation (0 = not done on the device) */
+    mv32 state_out[2];
     int32_t done;                       /* written last: launch id when the job's results are complete, -launch id when it was aborted */
 } h264e_hostdone_t;
 
@@ -161,7 +176,13 @@ typedef struct
     const mv32 *clusters_per_mb;        /* ... or, when not NULL, an exact per-macroblock trajectory [nmb][2] */
     uint16_t qdat[2][42];               /* quantizer tables (h264-lab.h:5839-5912), built by the host */
     int launch_id;                      /* > 0, unique per submit */
-    const int *abort_word;              /* host-mapped, or NULL: the job stops once *abort_word == launch_id */
+    const int *abort_word;              /* device memory, or NULL: the job stops once *abort_word == launch_id (raised by a finalizer whose walk
+                                           failed, or by the host) */
+    int walk_on_device;                 /* the finalizer validates the mv_clusters speculation itself */
+    mv32 exact_state[2];                /* ... from this exact state when walk_prev is NULL (first job of the launch) */
+    const h264e_walkrec_t *walk_prev;   /* ... else from the verdict of the job before it in stream order (same launch) */
+    h264e_walkrec_t *walk_out;          /* this job's verdict */
+    mv32 *traj_out;                     /* [nmb][2] the exact state in front of every macroblock, as walked (input of a re-encode) */
     h264e_hostdone_t *host_done;        /* host-mapped result record, or NULL */
     uint8_t *host_rbsp;                 /* host-mapped copy of the RBSP (capacity host_rbsp_cap), or NULL */
     uint32_t host_rbsp_cap;

@@ -806,10 +806,14 @@ struct H264E_clip_tag
     int pending_avail;                      /* ... once the asynchronous uploads in flight have landed */
     void (*idle_hook)(void *token); void *idle_token;   /* called while the encoder waits for the GPU (the app feeds uploads from it) */
     int32_t state[2];                       /* exact mv_clusters in front of frame `next` */
-    int32_t *first_arr;                     /* per-macroblock trajectory for a frame that is encoded again, or NULL */
+    int first_dev;                          /* the next launch's first frame is encoded again with the per-macroblock trajectory its walk left on the device */
+    int32_t *first_arr;                     /* (unused by the streaming path since the walk moved to the device; kept NULL) */
     int first_row;                          /* ... which restarts at this macroblock row */
     int32_t after[2]; int have_after;       /* predicted state behind that frame */
     int narrow;                             /* reference-window geometry in use (h264e_dev.h) */
+    int narrow_ok;                          /* the picture size allows the narrow geometry at all */
+    int wide_until, wide_hold;              /* wide geometry until this frame; length of the next wide spell (doubles when narrow fails again) */
+    long long far_acc; int far_frames;      /* far reads / frames since the last decision */
     rc_t rcs; int rc_frame, rc_qp;          /* rate control: state, the frame rc_frame_start has run for, its QP */
     /* keep_records: what every accepted frame consumed, so that a different start state can be validated later (GOP shards) */
     h264e_hip_mbrec_t **rec_store;          /* [nframes] macroblock records of the accepted encode, or NULL */
@@ -834,12 +838,13 @@ void H264E_clip_rewind(H264E_clip_t *c)
     if (!c) return;
     c->next = 0;
     c->state[0] = c->par.mv_clusters_in[0]; c->state[1] = c->par.mv_clusters_in[1];
-    free(c->first_arr); c->first_arr = NULL;
+    free(c->first_arr); c->first_arr = NULL; c->first_dev = 0;
     c->first_row = 0; c->have_after = 0;
     /* reference-window geometry (h264e_dev.h): narrow = consecutive frames 4 macroblock steps apart, as long as vectors rarely
      * reach more than 12 samples right / down of their macroblock; wide (7 steps) for the rest of the clip otherwise.  Large
      * pictures already fill the GPU's resident workgroups with the wide geometry: the narrow one only pays below ~12k macroblocks */
-    c->narrow = (getenv("H264E_WIDE_WINDOW") || c->seq.nmb > 12000) ? 0 : 1;
+    c->narrow_ok = c->narrow = (getenv("H264E_WIDE_WINDOW") || c->seq.nmb > 12000) ? 0 : 1;
+    c->wide_until = 0; c->wide_hold = 30; c->far_acc = 0; c->far_frames = 0;
     memset(&c->rcs, 0, sizeof(c->rcs));
     c->rc_frame = -1; c->rc_qp = c->par.qp;
 }
@@ -1034,7 +1039,7 @@ int H264E_clip_restart(H264E_clip_t *c, int frame, const int32_t state[2])
     c->next = frame;
     if (c->resident < c->nframes) c->avail = c->pending_avail = frame;      /* a ring: the inputs from here on have to be uploaded again */
     c->state[0] = state[0]; c->state[1] = state[1];
-    free(c->first_arr); c->first_arr = NULL;
+    free(c->first_arr); c->first_arr = NULL; c->first_dev = 0;
     c->first_row = 0; c->have_after = 0;
     c->rc_frame = -1;
     return 0;
@@ -1103,8 +1108,13 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             /* frame 0 of the launch gets the exact state; the frames behind it the best prediction of what it leaves */
             t->mv_clusters[0] = used[i][0] = (i && c->have_after) ? c->after[0] : c->state[0];
             t->mv_clusters[1] = used[i][1] = (i && c->have_after) ? c->after[1] : c->state[1];
-            t->mv_clusters_per_mb = (i == 0) ? c->first_arr : NULL;
-            t->first_row = (i == 0 && c->first_arr) ? c->first_row : 0;
+            /* validation on the device: the frame's finalizer walks its records exactly (task 0 from the exact state, the others from
+             * the verdict in front of them) and stops the launch itself when a macroblock consumed the wrong candidates */
+            t->walk_on_device = 1;
+            t->exact_state[0] = c->state[0]; t->exact_state[1] = c->state[1];
+            t->mv_clusters_per_mb = NULL;
+            t->traj_from_device = (i == 0) && c->first_dev;
+            t->first_row = (i == 0 && c->first_dev) ? c->first_row : 0;
             t->narrow_window = c->narrow;
         }
         stats.rounds++;
@@ -1116,9 +1126,11 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
         /* consume the frames in stream order while the launch is still running */
         for (i = 0; i < F; i++)
         {
-            const int f = n + i, key = (f % G) == 0, slot = f % K, per_mb = (i == 0 && c->first_arr != NULL);
+            const int f = n + i, key = (f % G) == 0, slot = f % K, per_mb = (i == 0 && c->first_dev);
             h264e_hip_result_t r1;
             int dn, idle = 0;
+            int32_t cc[2];
+            memset(&r1, 0, sizeof(r1));
             while ((dn = h264e_hip_stream_done(c->pool, slot, &r1)) == 0)
             {
                 if (!h264e_hip_busy(c->pool) && ++idle > 2) break;      /* the launch ended without finishing this job */
@@ -1126,6 +1138,18 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
                 sched_yield();
             }
             if (dn == 0) dn = h264e_hip_stream_done(c->pool, slot, &r1);
+            if (dn == 2 && r1.walk_status == 2)
+            {
+                /* the device's exact walk found a macroblock of this frame that consumed other rounded candidates than the exact
+                 * ones and stopped the launch.  Every macroblock before first_bad consumed the right ones: its row and
+                 * the rows above are bit-identical in the next encode and are kept; the frame goes again from that row with the
+                 * walked per-macroblock trajectory (it stays on the device), the frames behind it with the walk's end state */
+                c->first_row = r1.first_bad/c->seq.nmbx;
+                c->first_dev = 1;
+                c->after[0] = r1.state_out[0]; c->after[1] = r1.state_out[1]; c->have_after = 1;
+                stats.reencoded_gops++;             /* counts relaunches */
+                break;
+            }
             if (dn != 1)
             {
                 if (dn < 0) goto done;
@@ -1137,26 +1161,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             if (i == 0) { t_first = t_last; far_reads = 0; }
             far_reads += r1.far_reads;
             if (r1.overflow) { snprintf(g_host_err, sizeof(g_host_err), "bit buffer overflow (frame %d)", f); (void)h264e_hip_stream_abort(c->pool); (void)h264e_hip_sync(c->pool); goto done; }
-            int32_t cc[2] = { c->state[0], c->state[1] };       /* state behind this frame, committed once the frame is accepted */
-            if (per_mb || r1.clusters_moved || used[i][0] != c->state[0] || used[i][1] != c->state[1])
-            {
-                /* exact walk: does every consumed (rounded) candidate equal what the kernel was given? */
-                const int first_bad = clusters_walk(cc, h264e_hip_stream_mbrec(c->pool, slot), c->seq.nmbx, c->seq.nmby, nslices, per_mb ? c->first_arr : used[i], per_mb, c->traj);
-                if (first_bad >= 0)
-                {
-                    /* every macroblock before first_bad consumed exactly the right candidates: its row and the rows above
-                     * it are bit-identical in the next encode and are kept */
-                    c->first_row = first_bad/c->seq.nmbx;
-                    /* frames from here on are void: stop the launch, go again with exact per-macroblock values for this one */
-                    if (h264e_hip_stream_abort(c->pool)) goto done;
-                    if (!c->first_arr) c->first_arr = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb);
-                    if (!c->first_arr) goto done;
-                    memcpy(c->first_arr, c->traj, sizeof(int32_t)*2*(size_t)nmb);
-                    c->after[0] = cc[0]; c->after[1] = cc[1]; c->have_after = 1;     /* the walk's end: what this frame most likely leaves behind */
-                    stats.reencoded_gops++;             /* counts relaunches */
-                    break;
-                }
-            }
+            cc[0] = r1.state_out[0]; cc[1] = r1.state_out[1];      /* exact state behind this frame (device walk), committed once the frame is accepted */
             t0 = now_ms();
             {
                 /* the frame as the kernel exported it: complete NALs (start codes and emulation prevention done on the device) */
@@ -1192,10 +1197,14 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
                 memcpy(c->rec_store[f], h264e_hip_stream_mbrec(c->pool, slot), rb);
                 c->used_store[f][0] = used[i][0]; c->used_store[f][1] = used[i][1];
                 free(c->permb_store[f]); c->permb_store[f] = NULL;
-                if (per_mb) { c->permb_store[f] = c->first_arr; c->first_arr = NULL; }
+                if (per_mb)
+                {
+                    c->permb_store[f] = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)nmb);
+                    if (!c->permb_store[f] || h264e_hip_stream_fetch_traj(c->pool, slot, 1, c->permb_store[f])) goto done;
+                }
             }
             c->state[0] = cc[0]; c->state[1] = cc[1];
-            if (i == 0 && c->first_arr) { free(c->first_arr); c->first_arr = NULL; }
+            if (i == 0) c->first_dev = 0;
             stats.assemble_ms += now_ms() - t0;
             nvalid++;
         }
@@ -1207,8 +1216,23 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             if (h264e_hip_ssd_frames(c->pool, nvalid, n % c->resident, c->resident, n % K, K, c->ssd_out + 3*(size_t)(n - first))) goto done;
         }
         c->next = n + nvalid;
-        /* more than one macroblock in eight left the narrow window: the wide one pays from here on */
-        if (c->narrow && nvalid > 0 && far_reads > (long long)nvalid*nmb/8) c->narrow = 0;
+        /* Window geometry for the next launch.  More than one macroblock in eight leaving the narrow window over at least 8 frames:
+         * the wide one pays -- for a while: such motion is often a transient (a scene cut, an object wrapping around), so the narrow
+         * geometry is tried again after wide_hold frames, a spell that doubles every time it fails again. */
+        if (c->narrow)
+        {
+            c->far_acc += far_reads; c->far_frames += nvalid;
+            if (c->far_frames >= 8)
+            {
+                if (c->far_acc > (long long)c->far_frames*nmb/8)
+                {
+                    c->narrow = 0;
+                    c->wide_until = c->next + c->wide_hold;
+                    c->wide_hold = imin(c->wide_hold*2, 960);
+                } else if (c->far_frames >= 64) c->wide_hold = 30;
+                c->far_acc = 0; c->far_frames = 0;
+            }
+        } else if (c->narrow_ok && c->next >= c->wide_until) { c->narrow = 1; c->far_acc = 0; c->far_frames = 0; }
         if (getenv("H264E_DEBUG"))
             fprintf(stderr, "clip launch %d (first row %d, %s window, %lld far reads): %d frames in flight, %d valid, next %d; first frame after %.2f ms, then %.3f ms/frame, drained %.2f ms after the last\n",
                     stats.rounds, tasks[0].first_row, tasks[0].narrow_window ? "narrow" : "wide", far_reads, F, nvalid, c->next, t_first - t_submit, nvalid > 1 ? (t_last - t_first)/(nvalid - 1 + (nvalid < F)) : 0.0, now_ms() - t_last);

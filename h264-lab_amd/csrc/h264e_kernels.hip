@@ -75,21 +75,82 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
     {
         /* ---- finalizer */
         int st = 0, seen = 0;
+        GLOBAL_AS h264e_hostdone_t *hd = (GLOBAL_AS h264e_hostdone_t *)T.host_done;
+        GLOBAL_AS h264e_walkrec_t *wout = (GLOBAL_AS h264e_walkrec_t *)T.walk_out;
         for (int r = G.nmby - 1; r >= 0 && !st; r--) st = poll_progress(C.progress + r, G.nmbx + 1, seen, G.spin_limit);
         if (st)
         {
             if (threadIdx.x == 0)
             {
                 if (st == -1) *errflag = 1;
-                if (T.host_done) __hip_atomic_store(&((GLOBAL_AS h264e_hostdone_t *)T.host_done)->done, -T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (T.walk_on_device && wout)
+                {
+                    /* the frames behind wait for this verdict: never leave them spinning */
+                    wout->status = H264E_WALK_VOID; wout->first_bad = -1;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&wout->flag, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (hd) { hd->walk_status = H264E_WALK_VOID; __hip_atomic_store(&hd->done, -T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
             }
             return;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        int wstatus = 0, first_bad = -1;
+        mv32 ws[2] = { T.exact_state[0], T.exact_state[1] };
+        if (T.walk_on_device)
+        {
+            /* exact mv_clusters validation on the device: start from the verdict of the frame in front (same launch), walk this
+             * frame's records, publish the verdict for the frame behind; a mismatch stops the whole launch through the abort word */
+            if (T.walk_prev)
+            {
+                const GLOBAL_AS h264e_walkrec_t *wp = (const GLOBAL_AS h264e_walkrec_t *)T.walk_prev;
+                int sf = 0;
+                if (poll_progress(&wp->flag, T.launch_id, sf, G.spin_limit)) wstatus = H264E_WALK_VOID;
+                else
+                {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (uni(wp->status) != H264E_WALK_OK) wstatus = H264E_WALK_VOID;
+                    else { ws[0] = (mv32)uni(wp->state_out[0]); ws[1] = (mv32)uni(wp->state_out[1]); }
+                }
+            }
+            if (!wstatus)
+            {
+                first_bad = device_clusters_walk(G, T, C.mbrec + (size_t)T.frame_slot*G.nmb, ws, (GLOBAL_AS mv32 *)T.traj_out);
+                wstatus = first_bad >= 0 ? H264E_WALK_BAD : H264E_WALK_OK;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0 && wout)
+            {
+                wout->state_out[0] = ws[0]; wout->state_out[1] = ws[1]; wout->status = wstatus; wout->first_bad = first_bad;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&wout->flag, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (wstatus != H264E_WALK_OK)
+            {
+                if (threadIdx.x == 0)
+                {
+                    if (wstatus == H264E_WALK_BAD && T.abort_word)
+                        __hip_atomic_store((GLOBAL_AS int *)T.abort_word, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (hd)
+                    {
+                        hd->walk_status = wstatus; hd->first_bad = first_bad; hd->state_out[0] = ws[0]; hd->state_out[1] = ws[1];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_store(&hd->done, -T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+                return;
+            }
+        }
         finalize_frame(G, C, T, (GLOBAL_AS int *)stepflags + 2*job);
-        if (T.host_done)
+        if (hd)
         {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -102,12 +163,12 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
             if (threadIdx.x == 0)
             {
                 const GLOBAL_AS h264e_frameout_t &F = C.fout[T.frame_slot];
-                GLOBAL_AS h264e_hostdone_t *hd = (GLOBAL_AS h264e_hostdone_t *)T.host_done;
                 hd->nbytes = nal_total; hd->all_skipped = F.all_skipped;
                 hd->nslices = F.nslices; hd->in_device = in_device;
 #pragma unroll
                 for (int k = 0; k < H264E_MAX_SLICES; k++) hd->slice_nbytes[k] = nal_bytes[k];
                 hd->clusters_moved = F.clusters_moved; hd->overflow = F.overflow | exp_overflow; hd->far_reads = F.far_reads;
+                hd->walk_status = wstatus; hd->first_bad = first_bad; hd->state_out[0] = ws[0]; hd->state_out[1] = ws[1];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                 /* system scope: the host reads these */
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(&hd->done, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -151,8 +212,8 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
         const int need = row > row0 ? imin(x + 2, G.nmbx) : 0;
         const int need_dep = RT.dep_progress ? imin(x + DEP_COLS, G.nmbx) : 0;     /* temporal wavefront: h264e_dev.h */
         int st = 0;
-        /* the abort word lives in host memory (one PCIe read): look at it every 8th macroblock only */
-        if ((x & 7) == 0 && abort_word && uni(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == launch_id) st = -2;
+        /* the abort word lives in device memory (raised by a finalizer whose mv_clusters walk failed, or by the host): one L2 read per macroblock */
+        if (abort_word && uni(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == launch_id) st = -2;
         /* temporal dependency first, then the loads that only need it (input, reference window) ... */
         if (!st && seen_dep < need_dep)
         {
@@ -313,7 +374,11 @@ struct h264e_hip_pool
     uint8_t **host_rbsp;                 /* [nchains], each host_rbsp_cap bytes */
     h264e_hip_mbrec_t **host_mbrec;      /* [nchains], each nmb records */
     uint32_t host_rbsp_cap;
-    int *abort_word;                     /* host-mapped */
+    int *abort_word;                     /* host-mapped: source of the host's own abort request */
+    int *abort_dev;                      /* device: the word the kernel polls */
+    h264e_walkrec_t *walkrec;            /* device [nchains] */
+    int32_t **traj_dev;                  /* per chain: two [nmb][2] trajectory buffers behind each other */
+    int *traj_cur;                       /* per chain: which of the two holds the latest device walk */
     unsigned long long *ssd_dev;         /* [nchains][3] sums of squared differences (h264e_hip_ssd_frames) */
     uint8_t *heap; size_t heap_bytes;    /* ONE device allocation; every device buffer of the pool is carved out of it */
     uint8_t *hheap; size_t hheap_bytes;  /* ONE host-mapped allocation for the streaming mirrors */
@@ -364,7 +429,7 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
         if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     }
 #endif
-    free(p->chains_host); free(p->clu_dev); free(p->ref_sel);
+    free(p->chains_host); free(p->clu_dev); free(p->ref_sel); free(p->traj_dev); free(p->traj_cur);
     free(p);
 }
 
@@ -404,6 +469,8 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     p->chains_host = (h264e_chain_dev_t *)calloc((size_t)nchains, sizeof(h264e_chain_dev_t));
     p->clu_dev = (int32_t **)calloc((size_t)nchains, sizeof(int32_t *));
     p->ref_sel = (int *)calloc((size_t)nchains, sizeof(int));
+    p->traj_dev = (int32_t **)calloc((size_t)nchains, sizeof(int32_t *));
+    p->traj_cur = (int *)calloc((size_t)nchains, sizeof(int));
     p->slot_launch = (int *)calloc((size_t)nchains, sizeof(int));
     p->host_rbsp = (uint8_t **)calloc((size_t)nchains, sizeof(uint8_t *));
     p->host_mbrec = (h264e_hip_mbrec_t **)calloc((size_t)nchains, sizeof(h264e_hip_mbrec_t *));
@@ -430,6 +497,8 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         p->progress_all = (int *)carve(sizeof(int)*(size_t)nchains*G.nmby, 256);
         p->errflag = (int *)carve(sizeof(int), 256);
         p->stepflags = (int *)carve(sizeof(int)*2*(size_t)nchains, 256);
+        p->abort_dev = (int *)carve(64, 256);
+        p->walkrec = (h264e_walkrec_t *)carve(sizeof(h264e_walkrec_t)*(size_t)nchains, 256);
         p->ssd_dev = (unsigned long long *)carve(sizeof(unsigned long long)*3*(size_t)nchains, 256);
         p->order = (uint32_t *)carve(sizeof(uint32_t)*2*(size_t)nchains*(G.nmby + 1), 256);
         p->host_done = (h264e_hostdone_t *)hcarve(sizeof(h264e_hostdone_t)*(size_t)nchains);
@@ -459,6 +528,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
             C.prof = (unsigned long long *)carve(sizeof(unsigned long long)*32, 256);
             C.far_reads = (int *)carve(16, 256);
             p->clu_dev[c] = (int32_t *)carve(sizeof(int32_t)*2*(size_t)G.nmb, 256);      /* per-macroblock mv_clusters array of a re-encode */
+            p->traj_dev[c] = slots == 1 ? (int32_t *)carve(sizeof(int32_t)*4*(size_t)G.nmb, 256) : 0;   /* two walk trajectories (device-side validation) */
             if (slots == 1)        /* streaming pools keep one result per chain slot: give each a host-mapped mirror */
             {
                 p->host_rbsp[c] = (uint8_t *)hcarve(p->host_rbsp_cap + 64);
@@ -744,9 +814,17 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
                 d.host_done = p->host_done + t.slot;
                 d.host_rbsp = p->host_rbsp[t.slot]; d.host_rbsp_cap = p->host_rbsp_cap;
                 d.host_mbrec = (h264e_mbrec_t *)p->host_mbrec[t.slot];
-                d.abort_word = p->abort_word;
+                d.abort_word = p->abort_dev;
                 p->host_done[t.slot].done = 0;
                 p->slot_launch[t.slot] = launch_id;
+                if (t.walk_on_device && p->traj_dev[t.slot])
+                {
+                    d.walk_on_device = 1;
+                    d.exact_state[0] = t.exact_state[0]; d.exact_state[1] = t.exact_state[1];
+                    d.walk_out = p->walkrec + t.slot;
+                    d.walk_prev = (c > 0 && tasks[c - 1].active && tasks[c - 1].stream_mode && tasks[c - 1].walk_on_device) ? p->walkrec + tasks[c - 1].slot : 0;
+                    d.traj_out = p->traj_dev[t.slot] + (size_t)(p->traj_cur[t.slot] ^ 1)*2*G.nmb;
+                }
             }
             for (int k = 0; k < 3; k++)
             {
@@ -788,7 +866,9 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         }
         d.clusters[0] = t.mv_clusters[0]; d.clusters[1] = t.mv_clusters[1];
         d.clusters_per_mb = 0;
-        if (t.mv_clusters_per_mb)
+        if (t.stream_mode && t.traj_from_device && p->traj_dev[t.slot])
+            d.clusters_per_mb = p->traj_dev[t.slot] + (size_t)p->traj_cur[t.slot]*2*G.nmb;     /* the latest device walk of this slot */
+        else if (t.mv_clusters_per_mb)
         {
             const size_t n = sizeof(int32_t)*2*(size_t)G.nmb;
             const int cs = t.stream_mode ? t.slot : c;
@@ -806,6 +886,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         }
         memcpy(d.qdat, t.qdat, sizeof(d.qdat));
         d.launch_id = launch_id;
+        if (d.walk_on_device) p->traj_cur[t.slot] ^= 1;         /* this launch's walk writes the other buffer: it is the latest from now on */
     }
     if (!any) { free(host); return 0; }
     if (any_narrow && any_wide) { free(host); FAIL("submit: the jobs of one launch must agree on narrow_window"); }
@@ -832,18 +913,46 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             row_end(*L, G, C, row);
             free(L);
         }
-        finalize_frame(G, C, T, p->stepflags + 2*c);
-        if (T.host_done)
         {
-            uint32_t nal_bytes[H264E_MAX_SLICES], nal_total = 0;
-            int exp_overflow = 0, in_device = 0;
-            export_frame(G, C, T, nal_bytes, nal_total, exp_overflow, in_device);
-            const h264e_frameout_t &F = C.fout[T.frame_slot];
-            T.host_done->nbytes = nal_total; T.host_done->all_skipped = F.all_skipped;
-            T.host_done->nslices = F.nslices; T.host_done->in_device = in_device;
-            for (int k = 0; k < H264E_MAX_SLICES; k++) T.host_done->slice_nbytes[k] = nal_bytes[k];
-            T.host_done->clusters_moved = F.clusters_moved; T.host_done->overflow = F.overflow | exp_overflow; T.host_done->far_reads = F.far_reads;
-            T.host_done->done = T.launch_id;
+            int wstatus = 0, first_bad = -1;
+            mv32 ws[2] = { T.exact_state[0], T.exact_state[1] };
+            if (T.walk_on_device)
+            {
+                if (T.walk_prev)
+                {
+                    if (T.walk_prev->flag != T.launch_id || T.walk_prev->status != H264E_WALK_OK) wstatus = H264E_WALK_VOID;
+                    else { ws[0] = T.walk_prev->state_out[0]; ws[1] = T.walk_prev->state_out[1]; }
+                }
+                if (!wstatus)
+                {
+                    first_bad = device_clusters_walk(G, T, C.mbrec + (size_t)T.frame_slot*G.nmb, ws, T.traj_out);
+                    wstatus = first_bad >= 0 ? H264E_WALK_BAD : H264E_WALK_OK;
+                }
+                if (T.walk_out) { T.walk_out->state_out[0] = ws[0]; T.walk_out->state_out[1] = ws[1]; T.walk_out->status = wstatus; T.walk_out->first_bad = first_bad; T.walk_out->flag = T.launch_id; }
+                if (wstatus != H264E_WALK_OK)
+                {
+                    if (T.host_done)
+                    {
+                        T.host_done->walk_status = wstatus; T.host_done->first_bad = first_bad; T.host_done->state_out[0] = ws[0]; T.host_done->state_out[1] = ws[1];
+                        T.host_done->done = -T.launch_id;
+                    }
+                    continue;
+                }
+            }
+            finalize_frame(G, C, T, p->stepflags + 2*c);
+            if (T.host_done)
+            {
+                uint32_t nal_bytes[H264E_MAX_SLICES], nal_total = 0;
+                int exp_overflow = 0, in_device = 0;
+                export_frame(G, C, T, nal_bytes, nal_total, exp_overflow, in_device);
+                const h264e_frameout_t &F = C.fout[T.frame_slot];
+                T.host_done->nbytes = nal_total; T.host_done->all_skipped = F.all_skipped;
+                T.host_done->nslices = F.nslices; T.host_done->in_device = in_device;
+                for (int k = 0; k < H264E_MAX_SLICES; k++) T.host_done->slice_nbytes[k] = nal_bytes[k];
+                T.host_done->clusters_moved = F.clusters_moved; T.host_done->overflow = F.overflow | exp_overflow; T.host_done->far_reads = F.far_reads;
+                T.host_done->walk_status = wstatus; T.host_done->first_bad = first_bad; T.host_done->state_out[0] = ws[0]; T.host_done->state_out[1] = ws[1];
+                T.host_done->done = T.launch_id;
+            }
         }
     }
 #else
@@ -902,16 +1011,32 @@ extern "C" int h264e_hip_stream_done(h264e_hip_pool_t *p, int slot, h264e_hip_re
     if (!p || slot < 0 || slot >= p->nchains || !p->host_rbsp[slot]) FAIL("stream_done: bad argument");
     const volatile h264e_hostdone_t *d = p->host_done + slot;
     const int v = d->done;
-    if (v == -p->slot_launch[slot]) return 2;               /* the job was aborted */
-    if (v != p->slot_launch[slot]) return 0;                /* not yet */
+    if (v != p->slot_launch[slot] && v != -p->slot_launch[slot]) return 0;      /* not yet */
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     if (res)
     {
-        res->nbytes = d->nbytes; res->all_skipped = d->all_skipped; res->clusters_moved = d->clusters_moved; res->overflow = d->overflow; res->far_reads = d->far_reads;
-        res->nslices = d->nslices; res->in_device = d->in_device;
-        for (int k = 0; k < H264E_HIP_MAX_SLICES; k++) res->slice_nbytes[k] = d->slice_nbytes[k];
+        res->walk_status = d->walk_status; res->first_bad = d->first_bad; res->state_out[0] = d->state_out[0]; res->state_out[1] = d->state_out[1];
+        if (v > 0)
+        {
+            res->nbytes = d->nbytes; res->all_skipped = d->all_skipped; res->clusters_moved = d->clusters_moved; res->overflow = d->overflow; res->far_reads = d->far_reads;
+            res->nslices = d->nslices; res->in_device = d->in_device;
+            for (int k = 0; k < H264E_HIP_MAX_SLICES; k++) res->slice_nbytes[k] = d->slice_nbytes[k];
+        }
     }
-    return 1;
+    return v > 0 ? 1 : 2;                                   /* 2: the job was aborted (or failed its own validation: walk_status) */
+}
+
+extern "C" int h264e_hip_stream_fetch_traj(h264e_hip_pool_t *p, int slot, int consumed, int32_t *dst)
+{
+    if (!p || !dst || slot < 0 || slot >= p->nchains || !p->traj_dev[slot]) FAIL("stream_fetch_traj: bad argument");
+    const int32_t *src = p->traj_dev[slot] + (size_t)(p->traj_cur[slot] ^ (consumed ? 1 : 0))*2*p->G.nmb;
+#ifdef H264E_EMU
+    memcpy(dst, src, sizeof(int32_t)*2*(size_t)p->G.nmb);
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpy(dst, src, sizeof(int32_t)*2*(size_t)p->G.nmb, hipMemcpyDeviceToHost));
+#endif
+    return 0;
 }
 
 extern "C" const uint8_t *h264e_hip_stream_rbsp(h264e_hip_pool_t *p, int slot)
@@ -956,6 +1081,13 @@ extern "C" int h264e_hip_stream_abort(h264e_hip_pool_t *p)
 {
     if (!p || !p->abort_word) FAIL("stream_abort: bad argument");
     __atomic_store_n(p->abort_word, p->launch_counter, __ATOMIC_RELEASE);
+#ifdef H264E_EMU
+    *p->abort_dev = p->launch_counter;
+#else
+    /* the kernel polls a word in device memory: copy the request there on the copy stream, next to the running launch */
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpyAsync(p->abort_dev, p->abort_word, sizeof(int), hipMemcpyHostToDevice, p->copy_stream));
+#endif
     return 0;
 }
 

@@ -52,6 +52,13 @@ typedef struct
     /* stream mode: encode this frame again from macroblock row first_row; the rows above it (bits, records, picture) are
      * kept from the previous encode of the same frame in the same slot (0 = whole frame) */
     int first_row;
+    /* stream mode: the job's finalizer validates the mv_clusters speculation ON THE DEVICE (exact walk over the frame's records,
+     * enc_row.h device_clusters_walk): task 0 of a submit starts from exact_state, task i from the verdict of task i-1; a mismatch
+     * stops the launch (device abort word) and is reported in the result (walk_status, first_bad, state_out); the walked
+     * per-macroblock trajectory stays on the device and becomes the candidates of a re-encode with traj_from_device */
+    int walk_on_device;
+    int32_t exact_state[2];
+    int traj_from_device;
     /* stream mode: 1 = narrow valid window (53 x 52 samples, consecutive frames 4 macroblock steps apart), 0 = the whole
      * 64 x 64 window (7 steps apart); see h264e_dev.h.  Same bits either way. */
     int narrow_window;
@@ -69,6 +76,9 @@ typedef struct
     int overflow;               /* a bit buffer overflowed: the result is invalid */
     int far_reads;              /* reference accesses that left the valid window and took the HBM path (stream mode) */
     int in_device;              /* the NALs did not fit the host-mapped mirror: h264e_hip_stream_fetch_nals() gets them */
+    int walk_status;            /* device-side validation: 0 not done, 1 ok, 2 this frame consumed wrong candidates (first_bad), 3 void (a frame before it failed) */
+    int first_bad;
+    int32_t state_out[2];       /* ok: exact mv_clusters behind the frame; bad: the walk's end state */
 } h264e_hip_result_t;
 
 typedef struct { int32_t mv0; int8_t type; uint8_t used_cand; uint8_t pad[2]; } h264e_hip_mbrec_t;
@@ -102,6 +112,9 @@ int  h264e_hip_step_flags(h264e_hip_pool_t *pool, int *flags /* [nchains][2] */)
 int  h264e_hip_stream_done(h264e_hip_pool_t *pool, int slot, h264e_hip_result_t *res);
 const uint8_t *h264e_hip_stream_rbsp(h264e_hip_pool_t *pool, int slot);
 const h264e_hip_mbrec_t *h264e_hip_stream_mbrec(h264e_hip_pool_t *pool, int slot);
+/* a per-macroblock trajectory of `slot` ([nmb][2]): consumed = 0 the one its last device walk produced (what a re-encode with
+ * traj_from_device will consume), 1 the one its last encode consumed (traj_from_device) */
+int  h264e_hip_stream_fetch_traj(h264e_hip_pool_t *pool, int slot, int consumed, int32_t *dst);
 int  h264e_hip_stream_fetch_nals(h264e_hip_pool_t *pool, int slot, uint8_t *dst, uint32_t nbytes);
 /* resident input frames back to the host (measurement helper) */
 int  h264e_hip_download_i420(h264e_hip_pool_t *pool, int first, int nframes, uint8_t *host_i420);

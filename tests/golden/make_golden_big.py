@@ -38,6 +38,7 @@ CASES = {
     "cif_30_thr2": (352, 288, 30, "--qp 26 --gop 30 --threads 2", REF_THR),
     "cif_30_thr4": (352, 288, 30, "--qp 26 --gop 30 --threads 4", REF_THR),
     "1080p_30_thr8": (1920, 1080, 30, "--qp 26 --gop 30 --threads 8", REF_THR),
+    "bench_1080p_600_thr8": (1920, 1080, 600, "--qp 26 --gop 30 --threads 8", REF_THR),     # the bench clip as 8 row-band slices
     "8k_3_thr2": (7680, 4320, 3, "--qp 26 --gop 30 --threads 2", REF_THR),     # F6: the reference aborts at >= 3 slices at 8K
     "8k_3_thr2_kbps": (7680, 4320, 3, "--kbps 60000 --gop 30 --threads 2", REF_THR),   # configs[4]: multi-slice + rate control
     "1080p_20_thr8_kbps": (1920, 1080, 20, "--kbps 4000 --gop 30 --threads 8", REF_THR),
