@@ -477,6 +477,7 @@ static int step_exact(h264e_hip_pool_t *pool, int nchains, h264e_hip_task_t *tas
     if (extra_passes) *extra_passes = pass > 0 ? pass - 1 : 0;
     rc = 0;
 done:
+    if (rc) h264e_hip_release(pool);
     for (k = 0; k < nchains && arr; k++)
     {
         if (!rc && arr_out) arr_out[k] = arr[k]; else free(arr[k]);
@@ -1249,6 +1250,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
     if (out_bytes) *out_bytes = pos;
     rc = 0;
 done:
+    if (rc) h264e_hip_release(c->pool);         /* a failure between submit and sync: give the device's launch lock back */
     if (st) *st = stats;
     return rc;
 }

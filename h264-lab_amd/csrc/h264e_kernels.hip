@@ -283,6 +283,128 @@ __global__ void __launch_bounds__(64) h264e_nal_escape_selftest_kernel(uint8_t *
 }
 #endif
 
+/* ------------------------------------------------------------------ per-stage test hook (tests/test_stages.py)
+ * Runs ONE of the macroblock pipeline's wave-level stages on caller-supplied operands, so that each can be compared with the
+ * reference's own function of the same stage (tests/golden/stages.json, made by oracle/stage_harness.c):
+ *   1 SAD quadrants (wave_sad_ref_q)           in: picture 64x64 | block 16x16         args: x, y, window      out: int32 sad4[4], sum
+ *   2 luma quarter-sample (wave_interp_luma)   in: picture 64x64                       args: x, y, w, h, dx, dy, window   out: 16x16 (stride 16)
+ *   3 chroma bilinear (wave_interp_chroma)     in: picture 64x64 (used as U and V)     args: x, y, w, h, dx, dy           out: 16x16: U cols 0-7, V cols 8-15
+ *   4 transform/quant/dequant/recon            in: inp 256 | pred 256 | qdat 42 x u16  args: mode              out: int32 nz, dcflag | qblk_t q[16] | i16 dc[16] | i16 lev[16] | recon 256
+ *   5 CAVLC block (cavlc_block)                in: int16 coef[16]                      args: first, maxn, nctx out: int32 nnz, nbits | bytes
+ * `window` = 1 reads the reference samples through the LDS window like the macroblock loop, 0 through the HBM path.
+ */
+struct StageLds
+{
+    alignas(16) uint8_t win[WIN_W*WIN_STRIDE + 16];
+    alignas(16) uint8_t a[256], b[256], o[256];
+    alignas(16) qblk_t q[16];
+    alignas(4) int16_t dc[16], lev[16], coef[16];
+    alignas(4) uint16_t qdat[42];
+    CavlcTab ct;
+};
+#define STAGE_IN_MAX (4096 + 256 + 256)
+#define STAGE_OUT_MAX (8 + 16*64 + 32 + 32 + 256)
+DEV void stage_selftest(StageLds &S, int stage, const GLOBAL_AS uint8_t *in, const int *args, GLOBAL_AS uint8_t *out)
+{
+    int a[8];
+    for (int i = 0; i < 8; i++) a[i] = uni(args[i]);
+    Plane P = { (const gu8 *)in, 64, 64, 64 };
+    RefView R;
+    R.P = P; R.win = (const lu8 *)S.win; R.has_win = 0; R.wx0 = 0; R.wy0 = 0; R.dep = 0; R.nmbx = 4; R.nmby = 4; R.vw = WIN_W; R.vh = WIN_W;
+    R.far = 0; R.fail = 0; R.slice_row = 0; R.nslices = 0; R.spin_limit = 0;
+    GLOBAL_AS int32_t *oi = (GLOBAL_AS int32_t *)out;
+    if (stage == 1 || stage == 2)
+    {
+        const int x = a[0], y = a[1], window = stage == 1 ? a[2] : a[6];
+        if (window) { R.has_win = 1; R.wx0 = x - WIN_M; R.wy0 = y - WIN_M; wave_load_window(S.win, P, R.wx0, R.wy0, 0); wave_sync(); }
+        if (stage == 1)
+        {
+            int s4[4];
+            WAVE_FOR(l) { lds32_store(S.b + 4*l, gload32((const gu8 *)in + 4096 + 4*l)); }
+            wave_sync();
+            const int tot = wave_sad_ref_q(R, x, y, S.b, s4);
+            if (wave_lane() == 0) { oi[0] = s4[0]; oi[1] = s4[1]; oi[2] = s4[2]; oi[3] = s4[3]; oi[4] = tot; }
+        } else
+        {
+            WAVE_FOR(l) { lds32_store(S.o + 4*l, 0u); }
+            wave_sync();
+            wave_interp_luma(R, 0, 0, mvmk(4*x + a[4], 4*y + a[5]), a[2], a[3], S.o);
+            wave_sync();
+            WAVE_FOR(l) { gstore32((gu8 *)out + 4*l, lds32(S.o + 4*l)); }
+        }
+    } else if (stage == 3)
+    {
+        WAVE_FOR(l) { lds32_store(S.o + 4*l, 0u); }
+        wave_sync();
+        wave_interp_chroma(R, P, P, 0, 0, mvmk(8*a[0] + a[4], 8*a[1] + a[5]), a[2], a[3], S.o);
+        wave_sync();
+        WAVE_FOR(l) { gstore32((gu8 *)out + 4*l, lds32(S.o + 4*l)); }
+    } else if (stage == 4)
+    {
+        const int mode = a[0], side = mode >> 1;
+        WAVE_FOR(l)
+        {
+            lds32_store(S.a + 4*l, gload32((const gu8 *)in + 4*l));
+            lds32_store(S.b + 4*l, gload32((const gu8 *)in + 256 + 4*l));
+            if (l < 21) lds32_store((uint8_t *)S.qdat + 4*l, gload32((const gu8 *)in + 512 + 4*l));
+            if (l < 8) { lds32_store((uint8_t *)S.dc + 4*l, 0u); lds32_store((uint8_t *)S.lev + 4*l, 0u); }
+            for (int k = l; k < 256; k += 64) lds32_store((uint8_t *)S.q + 4*k, 0u);
+        }
+        wave_sync();
+        unsigned nz = wave_xform_quant(S.a, S.b, mode, S.q, S.dc, S.qdat);
+        int dcflag = 0;
+        wave_sync();
+        if (mode == QMODE_I16) quant_luma_dc(S.q, S.dc, S.lev, S.qdat);
+        if (mode == QMODE_CHROMA) dcflag = quant_chroma_dc(S.q, S.dc, S.lev, S.qdat);
+        wave_sync();
+        /* the operands as the reference has them in front of the reconstruction */
+        WAVE_FOR(l)
+        {
+            for (int k = l; k < 256; k += 64) gstore32((gu8 *)out + 8 + 4*k, lds32((const uint8_t *)S.q + 4*k));
+            if (l < 8) { gstore32((gu8 *)out + 8 + 1024 + 4*l, lds32((const uint8_t *)S.dc + 4*l)); gstore32((gu8 *)out + 8 + 1056 + 4*l, lds32((const uint8_t *)S.lev + 4*l)); }
+        }
+        /* reconstruction as mb_write / intra4_choose call it (h264-lab.h:4428-4433, 4468-4488, 4809-4811) */
+        WAVE_FOR(l) { lds32_store(S.o + 4*l, lds32(S.b + 4*l)); }
+        wave_sync();
+        if (mode == QMODE_INTER) wave_recon(S.o, 16, S.b, S.q, 4, nz << 16);
+        else if (mode == QMODE_I16) wave_recon(S.o, 16, S.b, S.q, 4, 0xffffu << 16);
+        else if (mode == QMODE_I4) { if (nz & 1) wave_recon(S.o, 16, S.b, S.q, 1, 0x80000000u); }
+        else if (dcflag | (int)nz)
+        {
+            unsigned m = nz;
+            if (dcflag)
+            {
+                WAVE_FOR(l) { if (l < 60) { const int b4 = l/15, i = 1 + l % 15; if (~nz & (8u >> b4)) S.q[b4].dq[i] = 0; } }
+                wave_sync();
+                m = 15;
+            }
+            wave_recon(S.o, 16, S.b, S.q, 2, m << 28);
+        }
+        wave_sync();
+        WAVE_FOR(l) { gstore32((gu8 *)out + 8 + 1088 + 4*l, lds32(S.o + 4*l)); }
+        if (wave_lane() == 0) { oi[0] = (int32_t)nz; oi[1] = dcflag; }
+        (void)side;
+    } else if (stage == 5)
+    {
+        cavlc_tab_load(S.ct);
+        WAVE_FOR(l) { if (l < 8) lds32_store((uint8_t *)S.coef + 4*l, gload32((const gu8 *)in + 4*l)); }
+        wave_sync();
+        BitW b;
+        b.acc = 0; b.nacc = 0; b.pos = 0; b.cap = 60; b.overflow = 0; b.buf = (GLOBAL_AS uint32_t *)(out + 8);
+        const int nnz = cavlc_block(b, S.ct, S.coef, a[0], a[1], a[2]);
+        const uint32_t nbits = bw_bits(b);
+        if (b.nacc) bw_put(b, 32 - b.nacc, 0);
+        if (wave_lane() == 0) { oi[0] = nnz; oi[1] = (int32_t)nbits; }
+    }
+}
+#ifndef H264E_EMU
+__global__ void __launch_bounds__(64) h264e_stage_selftest_kernel(int stage, const uint8_t *in, const int *args, uint8_t *out)
+{
+    __shared__ StageLds S;
+    stage_selftest(S, stage, (const GLOBAL_AS uint8_t *)in, args, (GLOBAL_AS uint8_t *)out);
+}
+#endif
+
 /* synth_v1 generator, one sample per call */
 DEV uint32_t sv_h32(uint32_t a)
 {
@@ -356,6 +478,19 @@ static void host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 #define TASK_RING 128
 
+/* One launch at a time per device, process-wide.  The macroblock kernel's forward-progress argument (every workgroup waits for
+ * workgroups dispatched before it, which are resident or finished) assumes the launch has the device's wave slots to itself: two
+ * such launches side by side can fill the slots with waiting workgroups of one while the workgroups they wait for sit undispatched
+ * behind the other's (measured: "bounded spin expired" with 3-4 concurrent clip encoders, tools/multi_clip_probe.py).  A pool takes
+ * its device's lock with its first submit and gives it back when its launches have drained (h264e_hip_sync / release / destroy). */
+#ifndef H264E_EMU
+#include <pthread.h>
+#define H264E_MAX_DEVICES 64
+static pthread_mutex_t g_device_lock[H264E_MAX_DEVICES] = { PTHREAD_MUTEX_INITIALIZER };
+static pthread_once_t g_device_lock_once = PTHREAD_ONCE_INIT;
+static void device_locks_init(void) { for (int i = 0; i < H264E_MAX_DEVICES; i++) pthread_mutex_init(&g_device_lock[i], 0); }
+#endif
+
 struct h264e_hip_pool
 {
     int device, nchains, frames_resident, slots;
@@ -383,6 +518,7 @@ struct h264e_hip_pool
     uint8_t *heap; size_t heap_bytes;    /* ONE device allocation; every device buffer of the pool is carved out of it */
     uint8_t *hheap; size_t hheap_bytes;  /* ONE host-mapped allocation for the streaming mirrors */
     int launch_counter;
+    int holds_device;                    /* this pool has launches in flight and owns its device's launch lock */
     int *slot_launch;                    /* per chain slot: launch id of its current job */
     int32_t **clu_dev;                   /* per chain: optional per-macroblock mv_clusters array */
     int *ref_sel;                        /* per chain */
@@ -409,6 +545,24 @@ extern "C" int h264e_hip_device_count(void)
 #endif
 }
 
+static void device_acquire(h264e_hip_pool_t *p)
+{
+#ifndef H264E_EMU
+    if (p->holds_device) return;
+    pthread_once(&g_device_lock_once, device_locks_init);
+    pthread_mutex_lock(&g_device_lock[(unsigned)p->device % H264E_MAX_DEVICES]);
+#endif
+    p->holds_device = 1;
+}
+static void device_release(h264e_hip_pool_t *p)
+{
+    if (!p->holds_device) return;
+    p->holds_device = 0;
+#ifndef H264E_EMU
+    pthread_mutex_unlock(&g_device_lock[(unsigned)p->device % H264E_MAX_DEVICES]);
+#endif
+}
+
 extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
 {
     if (!p) return;
@@ -417,6 +571,7 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->copy_stream) (void)hipStreamSynchronize(p->copy_stream);
 #endif
+    device_release(p);
     host_free(p->hheap);
     free(p->host_rbsp); free(p->host_mbrec); free(p->slot_launch);
     dev_free(p->heap);
@@ -750,7 +905,11 @@ extern "C" int h264e_hip_sync(h264e_hip_pool_t *p)
     if (!p) FAIL("sync: null pool");
 #ifndef H264E_EMU
     HIPCHK(hipSetDevice(p->device));
-    HIPCHK(hipStreamSynchronize(p->stream));
+    {
+        const hipError_t es = hipStreamSynchronize(p->stream);
+        device_release(p);              /* drained (or lost): the next launch on this device may go */
+        if (es != hipSuccess) FAIL("hipStreamSynchronize: %s", hipGetErrorString(es));
+    }
     for (int i = 0; i < p->ev_pending; i++)
     {
         float a = 0, b = 0;
@@ -767,8 +926,20 @@ extern "C" int h264e_hip_sync(h264e_hip_pool_t *p)
         FAIL("macroblock kernel gave up waiting for the row above (bounded spin expired)");
     }
 #endif
+    device_release(p);
     p->pending = 0;
     return 0;
+}
+
+/* give the device back after a failure in the middle of a launch sequence (no error reporting of its own) */
+extern "C" void h264e_hip_release(h264e_hip_pool_t *p)
+{
+    if (!p) return;
+#ifndef H264E_EMU
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+#endif
+    device_release(p);
 }
 
 extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tasks)
@@ -889,6 +1060,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         if (d.walk_on_device) p->traj_cur[t.slot] ^= 1;         /* this launch's walk writes the other buffer: it is the latest from now on */
     }
     if (!any) { free(host); return 0; }
+    device_acquire(p);                  /* one launch at a time per device (see g_device_lock) */
     if (any_narrow && any_wide) { free(host); FAIL("submit: the jobs of one launch must agree on narrow_window"); }
     h264e_frame_task_t *slot = p->tasks_dev + (size_t)p->ring_pos*p->nchains;
     p->ring_pos = (p->ring_pos + 1) % TASK_RING;
@@ -1271,6 +1443,37 @@ extern "C" int h264e_hip_selftest_nal_escape(h264e_hip_pool_t *p, const uint8_t 
     if (e != hipSuccess) FAIL("selftest_nal_escape: %s", hipGetErrorString(e));
     *out_n = res[0];
     return res[1] ? 1 : 0;
+#endif
+}
+
+extern "C" int h264e_hip_selftest_stage(h264e_hip_pool_t *p, int stage, const uint8_t *in, uint32_t nin, const int *args /* [8] */, uint8_t *out, uint32_t nout)
+{
+    if (!p || !in || !args || !out || stage < 1 || stage > 5 || nin > STAGE_IN_MAX || nout > STAGE_OUT_MAX) FAIL("selftest_stage: bad argument");
+#ifdef H264E_EMU
+    uint8_t *bi = (uint8_t *)calloc(1, STAGE_IN_MAX + 64), *bo = (uint8_t *)calloc(1, STAGE_OUT_MAX + 64);
+    StageLds *S = (StageLds *)calloc(1, sizeof(StageLds));
+    if (!bi || !bo || !S) { free(bi); free(bo); free(S); FAIL("out of host memory"); }
+    memcpy(bi, in, nin);
+    stage_selftest(*S, stage, bi, args, bo);
+    memcpy(out, bo, nout);
+    free(bi); free(bo); free(S);
+    return 0;
+#else
+    uint8_t *buf = 0;
+    HIPCHK(hipSetDevice(p->device));
+    if (hipMalloc((void **)&buf, STAGE_IN_MAX + STAGE_OUT_MAX + 256) != hipSuccess) FAIL("selftest_stage: device allocation failed");
+    hipError_t e = hipMemset(buf, 0, STAGE_IN_MAX + STAGE_OUT_MAX + 256);
+    if (e == hipSuccess) e = hipMemcpy(buf, in, nin, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(buf + STAGE_IN_MAX, args, 8*sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+    {
+        hipLaunchKernelGGL(h264e_stage_selftest_kernel, dim3(1), dim3(64), 0, p->stream, stage, (const uint8_t *)buf, (const int *)(buf + STAGE_IN_MAX), buf + STAGE_IN_MAX + 128);
+        e = hipStreamSynchronize(p->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, buf + STAGE_IN_MAX + 128, nout, hipMemcpyDeviceToHost);
+    (void)hipFree(buf);
+    if (e != hipSuccess) FAIL("selftest_stage: %s", hipGetErrorString(e));
+    return 0;
 #endif
 }
 

@@ -109,6 +109,9 @@ int  h264e_hip_step_flags(h264e_hip_pool_t *pool, int *flags /* [nchains][2] */)
  * copies its RBSP and macroblock records to host-mapped memory and raises a done word, so the host can consume frame
  * after frame while later frames of the same launch are still running.
  * h264e_hip_stream_done: 0 not finished, 1 finished (res filled), 2 aborted. */
+/* A pool owns its device's launch lock (process-wide, one persistent launch at a time per device) from its first submit until
+ * h264e_hip_sync returns; h264e_hip_release gives it back after a failure in between (waits for the stream, reports nothing). */
+void h264e_hip_release(h264e_hip_pool_t *pool);
 int  h264e_hip_stream_done(h264e_hip_pool_t *pool, int slot, h264e_hip_result_t *res);
 const uint8_t *h264e_hip_stream_rbsp(h264e_hip_pool_t *pool, int slot);
 const h264e_hip_mbrec_t *h264e_hip_stream_mbrec(h264e_hip_pool_t *pool, int slot);
@@ -152,6 +155,9 @@ int  h264e_hip_timer_stop(h264e_hip_pool_t *pool, double *ms);
  * dst receives start code + escaped payload, *out_n its size.  Used by tests with adversarial inputs (real streams need an
  * escape about once per 4 MB). */
 int  h264e_hip_selftest_nal_escape(h264e_hip_pool_t *pool, const uint8_t *src, uint32_t n, uint8_t *dst, uint32_t cap, uint32_t *out_n);
+/* test hook: one wave-level stage of the macroblock pipeline on caller-supplied operands (h264e_kernels.hip stage_selftest lists
+ * the stages and their operand layouts; tests/test_stages.py compares them with the reference's own functions) */
+int  h264e_hip_selftest_stage(h264e_hip_pool_t *pool, int stage, const uint8_t *in, uint32_t nin, const int *args /* [8] */, uint8_t *out, uint32_t nout);
 const char *h264e_hip_last_error(void);
 
 #ifdef __cplusplus

@@ -63,3 +63,40 @@ def test_row_bit_buffer_overflow_is_reported(P, monkeypatch):
         ce.encode()
     ce.close()
     assert "overflow" in str(ei.value)
+
+
+def test_concurrent_clip_encoders_on_one_device_take_turns(P):
+    """four host threads, four clip encoders, one GPU: launches of the persistent kernel must not run side by side (its
+    forward-progress argument needs the device's wave slots to itself -- unguarded, this very test ended in 'bounded spin expired');
+    the pools take turns through the per-device launch lock and every stream is still the golden one"""
+    import hashlib
+    import json
+    import os
+    import threading
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_big.json")))["bench_1080p_600"]
+    w, h, n = g["w"], g["h"], 150
+    encs = []
+    for b in range(4):
+        e = P.ClipEncoder(w, h, n, gop=30, qp=26)
+        e.generate_synth(0, n, t0=0, seed=1)
+        encs.append(e)
+    outs, errs = [None] * 4, []
+
+    def work(b):
+        try:
+            outs[b] = encs[b].encode()
+        except Exception as ex:  # noqa: BLE001 -- reported below
+            errs.append(repr(ex))
+
+    for rep in range(2):
+        th = [threading.Thread(target=work, args=(b,)) for b in range(4)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for out, sizes, st in outs:
+            assert sizes == g["frame_bytes"][:n] and len(out) == sum(sizes)
+    for e in encs:
+        e.close()
+    assert len(set(hashlib.md5(o[0]).hexdigest() for o in outs)) == 1
