@@ -63,6 +63,12 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
                                                          const h264e_frame_task_t *tasks, const uint32_t *order, int *errflag, int *stepflags)
 {
     __shared__ RowLds L;
+#ifdef H264E_LDS_PAD
+    /* diagnostic build (Makefile `halfres`): extra LDS per workgroup so that fewer workgroups fit a CU -- what single-stream throughput
+     * does when the resident rows are halved with the macroblock latency unchanged (the price of a multi-wave workgroup) */
+    __shared__ volatile char lds_pad[H264E_LDS_PAD];
+    if (G.nmbx < 0) lds_pad[threadIdx.x] = 1;
+#endif
     /* workgroups are dispatched in index order: `order` lists (job, row) by the step at which the row can start
      * (H264E_FRAME_LAG*job + 2*row), so the resident workgroups are the ones that can make progress */
     const uint32_t jr = order[blockIdx.x];
