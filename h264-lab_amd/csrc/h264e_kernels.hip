@@ -297,6 +297,8 @@ __global__ void __launch_bounds__(64) h264e_nal_escape_selftest_kernel(uint8_t *
  *   3 chroma bilinear (wave_interp_chroma)     in: picture 64x64 (used as U and V)     args: x, y, w, h, dx, dy           out: 16x16: U cols 0-7, V cols 8-15
  *   4 transform/quant/dequant/recon            in: inp 256 | pred 256 | qdat 42 x u16  args: mode              out: int32 nz, dcflag | qblk_t q[16] | i16 dc[16] | i16 lev[16] | recon 256
  *   5 CAVLC block (cavlc_block)                in: int16 coef[16]                      args: first, maxn, nctx out: int32 nnz, nbits | bytes
+ *   7 deblock one macroblock (wave_deblock)     in: luma tile 20x24 | U tile 10x12 | V tile 10x12 | bs 32   args: qp, qp_left, qp_top   out: the three tiles
+ *   6 intra 4x4 mode choice (wave_i4_choose)   in: edge 13 (L3..L0, UL, U0..U7) | block 4x4 stride 16   args: avail, mpred, penalty   out: int32 mode, cost | prediction 4x4 stride 16
  * `window` = 1 reads the reference samples through the LDS window like the macroblock loop, 0 through the HBM path.
  */
 struct StageLds
@@ -307,6 +309,12 @@ struct StageLds
     alignas(4) int16_t dc[16], lev[16], coef[16];
     alignas(4) uint16_t qdat[42];
     CavlcTab ct;
+    I4Scratch i4s;
+    DfTab df;
+    alignas(16) uint8_t yt[20*YT_STRIDE];
+    alignas(16) uint8_t ctile[2][10*CT_STRIDE];
+    alignas(4) uint8_t bs[32];
+    alignas(4) uint8_t nb[5*24];         /* the block's neighbourhood as intra4_choose keeps it: row stride 24, block at row 1, column 4 */
 };
 #define STAGE_IN_MAX (4096 + 256 + 256)
 #define STAGE_OUT_MAX (8 + 16*64 + 32 + 32 + 256)
@@ -401,6 +409,43 @@ DEV void stage_selftest(StageLds &S, int stage, const GLOBAL_AS uint8_t *in, con
         const uint32_t nbits = bw_bits(b);
         if (b.nacc) bw_put(b, 32 - b.nacc, 0);
         if (wave_lane() == 0) { oi[0] = nnz; oi[1] = (int32_t)nbits; }
+    } else if (stage == 6)
+    {
+        WAVE_FOR(l)
+        {
+            for (int k = l; k < 144; k += 64) S.i4s.lut[k] = k_i4_lut[k/16][k%16];
+            if (l < 13)
+            {
+                const uint8_t e = in[l];
+                if (l < 4) S.nb[24*(4 - l) + 3] = e;            /* L3..L0: the column left of the block, bottom-up */
+                else S.nb[3 + (l - 4)] = e;                     /* UL, U0..U7: the row above */
+            }
+            if (l < 16) lds32_store(S.a + 4*l, gload32((const gu8 *)in + 16 + 4*l));
+            if (l < 16) lds32_store(S.o + 4*l, 0u);
+        }
+        wave_sync();
+        const int res = wave_i4_choose(S.a, S.o, a[0], S.nb + 4, S.nb + 24 + 3, 24, a[1], a[2], S.i4s);
+        wave_sync();
+        WAVE_FOR(l) { if (l < 16) gstore32((gu8 *)out + 8 + 4*l, lds32(S.o + 4*l)); }
+        if (wave_lane() == 0) { oi[0] = res & 15; oi[1] = res >> 4; }
+    } else if (stage == 7)
+    {
+        const int ny = 20*YT_STRIDE, nc = 10*CT_STRIDE;
+        df_tab_load(S.df);
+        WAVE_FOR(l)
+        {
+            for (int k = l; k < ny; k += 64) S.yt[k] = in[k];
+            for (int k = l; k < nc; k += 64) { S.ctile[0][k] = in[ny + k]; S.ctile[1][k] = in[ny + nc + k]; }
+            if (l < 32) S.bs[l] = in[ny + 2*nc + l];
+        }
+        wave_sync();
+        wave_deblock(S.yt, S.ctile[0], S.ctile[1], S.bs, a[0], a[1], a[2], S.df);
+        wave_sync();
+        WAVE_FOR(l)
+        {
+            for (int k = l; k < ny; k += 64) out[k] = S.yt[k];
+            for (int k = l; k < nc; k += 64) { out[ny + k] = S.ctile[0][k]; out[ny + nc + k] = S.ctile[1][k]; }
+        }
     }
 }
 #ifndef H264E_EMU
@@ -1454,7 +1499,7 @@ extern "C" int h264e_hip_selftest_nal_escape(h264e_hip_pool_t *p, const uint8_t 
 
 extern "C" int h264e_hip_selftest_stage(h264e_hip_pool_t *p, int stage, const uint8_t *in, uint32_t nin, const int *args /* [8] */, uint8_t *out, uint32_t nout)
 {
-    if (!p || !in || !args || !out || stage < 1 || stage > 5 || nin > STAGE_IN_MAX || nout > STAGE_OUT_MAX) FAIL("selftest_stage: bad argument");
+    if (!p || !in || !args || !out || stage < 1 || stage > 7 || nin > STAGE_IN_MAX || nout > STAGE_OUT_MAX) FAIL("selftest_stage: bad argument");
 #ifdef H264E_EMU
     uint8_t *bi = (uint8_t *)calloc(1, STAGE_IN_MAX + 64), *bo = (uint8_t *)calloc(1, STAGE_OUT_MAX + 64);
     StageLds *S = (StageLds *)calloc(1, sizeof(StageLds));

@@ -11,6 +11,8 @@
  *   h264e_quant_luma_dc / _chroma_dc    h264-lab.h:2344/2355
  *   h264e_transform_add                 h264-lab.h:2638     reconstruction
  *   h264e_vlc_encode                    h264-lab.h:2775     one CAVLC residual block
+ *   h264e_intra_choose_4x4              h264-lab.h:1810     intra 4x4 mode decision: nine predictors, tie-breaks, prediction
+ *   df_strength + mb_deblock            h264-lab.h:5532/5642 boundary strengths of a macroblock and its in-loop filter (luma + chroma)
  *   rc_set_qp                           h264-lab.h:5839     the quantiser tables of a QP
  */
 #include <stdio.h>
@@ -230,6 +232,89 @@ int main(void)
         }
         hex("coef", q_in, 32, 0);
         hex("bits", buf, (nbits + 7)/8 + 4, 1);
+        printf("  }");
+        first = 0;
+    }
+    printf("\n ],\n");
+
+    /* ---- intra 4x4 mode choice: every neighbour availability, every predicted mode, edges from flat to steep */
+    printf(" \"intra4\": [\n");
+    first = 1;
+    for (i = 0; i < 160; i++)
+    {
+        ALIGN(16) static uint8_t in4[16*4] ALIGN2(16), pr4[16*4] ALIGN2(16);
+        ALIGN(4) uint8_t edge_store[16] ALIGN2(4);          /* [0..3] = L3..L0, [4] = UL, [5..12] = U0..U7 (h264-lab.h:1163-1175) */
+        uint8_t edge_in[16];
+        const int avail = (i < 16) ? i : (int)(rnd() % 16), mpred = (int)(rnd() % 9), penalty = (i % 5 == 0) ? 0 : (int)(rnd() % 40);
+        const int slope = (int)(rnd() % 7) - 3, base = 40 + (int)(rnd() % 160), noise = 1 + (int)(rnd() % 12);
+        int ret, y, x;
+        for (k = 0; k < 13; k++) { int v = base + slope*(k - 4)*3 + (int)(rnd() % (unsigned)(2*noise + 1)) - noise; edge_store[k] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+        for (k = 13; k < 16; k++) edge_store[k] = 0;
+        memset(in4, 0, sizeof(in4)); memset(pr4, 0, sizeof(pr4));
+        for (y = 0; y < 4; y++)
+            for (x = 0; x < 4; x++)
+            {
+                int v = base + slope*(x - y)*3 + (int)(rnd() % (unsigned)(2*noise + 1)) - noise;
+                if (i % 7 == 3) v = edge_store[5 + x];                          /* exactly vertical: ties between modes */
+                if (i % 7 == 5) v = edge_store[3 - y];                          /* exactly horizontal */
+                in4[16*y + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+            }
+        memcpy(edge_in, edge_store, sizeof(edge_in));
+        ret = h264e_intra_choose_4x4(in4, pr4, avail, edge_store + 5, mpred, penalty);
+        printf("%s  {\"avail\": %d, \"mpred\": %d, \"penalty\": %d, \"mode\": %d, \"cost\": %d,\n", first ? "" : ",\n", avail, mpred, penalty, ret & 15, ret >> 4);
+        hex("edge", edge_in, 13, 0);
+        hex("in", in4, 64, 0);
+        hex("pred", pr4, 64, 1);
+        printf("  }");
+        first = 0;
+    }
+    printf("\n ],\n");
+
+    /* ---- deblocking of one macroblock: strengths from df_strength, then mb_deblock on a 32x32 luma / 16x16 chroma neighbourhood
+     * (macroblock at (8,8) / (4,4)); macroblock types, coded-block flags, vectors and QPs vary */
+    printf(" \"deblock\": [\n");
+    first = 1;
+    for (i = 0; i < 36; i++)
+    {
+        static const int types[] = { -1, 0, 1, 2, 3, 5, 6 };
+        static uint8_t Yp[32*32], Up[16*16], Vp[16*16], Yin[32*32], Uin[16*16], Vin[16*16];        /* (U0.. are macros of the reference header) */
+        deblock_filter_t df, df2;
+        uint8_t dfqp[4], dfqp2[4], dfnz[4], dfnz2[4], strength[32];
+        int8_t mbt[4], mbt2[4];
+        H264E_io_yuv_t io;
+        const int mb_type = types[rnd() % 7], qp = 14 + (int)(rnd() % 36), amp = 2 + (int)(rnd() % 24);
+        memset(&df, 0, sizeof(df));
+        df.df_qp = dfqp + 1; df.mb_type = mbt + 1; df.df_nzflag = dfnz + 1;
+        for (k = 0; k < 4; k++)
+        {
+            int q2 = qp + (int)(rnd() % 7) - 3;
+            dfqp[k] = (uint8_t)(q2 < 10 ? 10 : q2 > 51 ? 51 : q2); mbt[k] = (int8_t)types[rnd() % 7]; dfnz[k] = (uint8_t)(rnd() % 16);
+        }
+        df.nzflag = (i % 4 == 0) ? 0 : (rnd() & 0x1ffffff) & ((rnd() & 1) ? 0x1ffffff : (rnd() & 0x1ffffff));
+        for (k = 0; k < 24; k++)
+        {
+            df.df_mv[k].s.x = (int16_t)(8 + ((rnd() % 5) == 0 ? (int)(rnd() % 9) - 4 : 0));
+            df.df_mv[k].s.y = (int16_t)(-4 + ((rnd() % 5) == 0 ? (int)(rnd() % 9) - 4 : 0));
+        }
+        fill_pic(Yp, 32, 32, amp); fill_pic(Up, 16, 16, amp/2 + 1); fill_pic(Vp, 16, 16, amp/2 + 1);
+        /* blocky content: steps at the 4x4 grid, which is what the filter is for */
+        for (k = 0; k < 32*32; k++) Yp[k] = (uint8_t)((Yp[k] >> 1) + 40 + (int)(((k & 31) >> 2) + ((k >> 5) >> 2))*((i % 3) + 1));
+        memcpy(Yin, Yp, sizeof(Yp)); memcpy(Uin, Up, sizeof(Up)); memcpy(Vin, Vp, sizeof(Vp));
+        /* the strengths this state gives (df_strength updates the state: run it on a copy) */
+        df2 = df; memcpy(dfqp2, dfqp, 4); memcpy(mbt2, mbt, 4); memcpy(dfnz2, dfnz, 4);
+        df2.df_qp = dfqp2 + 1; df2.mb_type = mbt2 + 1; df2.df_nzflag = dfnz2 + 1;
+        memset(strength, 0, sizeof(strength));
+        df_strength(&df2, mb_type, 1, strength, 0);
+        io.yuv[0] = Yp + 8*32 + 8; io.yuv[1] = Up + 4*16 + 4; io.yuv[2] = Vp + 4*16 + 4;
+        io.stride[0] = 32; io.stride[1] = 16; io.stride[2] = 16;
+        {
+            const int qp_left = dfqp[1], qp_top = dfqp[2];
+            mb_deblock(&df, mb_type, qp, 1, 1, &io, 0);
+            printf("%s  {\"mb_type\": %d, \"qp\": %d, \"qp_left\": %d, \"qp_top\": %d,\n", first ? "" : ",\n", mb_type, qp, qp_left, qp_top);
+        }
+        hex("bs", strength, 32, 0);
+        hex("y_in", Yin, sizeof(Yin), 0); hex("u_in", Uin, sizeof(Uin), 0); hex("v_in", Vin, sizeof(Vin), 0);
+        hex("y_out", Yp, sizeof(Yp), 0); hex("u_out", Up, sizeof(Up), 0); hex("v_out", Vp, sizeof(Vp), 1);
         printf("  }");
         first = 0;
     }

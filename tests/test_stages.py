@@ -141,6 +141,32 @@ def test_oracle_cavlc_block():
         assert buf.raw[:nb] == _b(c["bits"])[:nb], c
 
 
+def test_oracle_intra4_mode_choice():
+    L = _olib()
+    L.i4_choose.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    for c in FIX["intra4"]:
+        e = _b(c["edge"])
+        pred = C.create_string_buffer(64)
+        sad = C.c_int()
+        mode = L.i4_choose(_b(c["in"]), pred, c["avail"], e[5:13], bytes(reversed(e[0:4])), e[4], c["mpred"], c["penalty"], C.byref(sad))
+        assert (mode, sad.value) == (c["mode"], c["cost"]), c
+        want = np.frombuffer(_b(c["pred"]), np.uint8).reshape(4, 16)[:, :4]
+        assert (np.frombuffer(pred.raw, np.uint8).reshape(4, 16)[:, :4] == want).all(), c
+
+
+def _plane(h, n):
+    return np.frombuffer(_b(h), np.uint8).reshape(n, n).copy()
+
+
+def test_oracle_deblock_macroblock():
+    L = _olib()
+    L.deblock_mb.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]
+    for c in FIX["deblock"]:
+        y, u, v = _plane(c["y_in"], 32), _plane(c["u_in"], 16), _plane(c["v_in"], 16)
+        L.deblock_mb(y.ctypes.data + 8 * 32 + 8, 32, u.ctypes.data + 4 * 16 + 4, v.ctypes.data + 4 * 16 + 4, 16, _b(c["bs"]), c["qp"], c["qp_left"], c["qp_top"])
+        assert (y == _plane(c["y_out"], 32)).all() and (u == _plane(c["u_out"], 16)).all() and (v == _plane(c["v_out"], 16)).all(), (c["mb_type"], c["qp"], c["bs"])
+
+
 # ------------------------------------------------------------------ the kernel sources' stages (emulation build / GPU)
 
 def _hook(libpath):
@@ -195,6 +221,27 @@ def _check_stages(run):
         words = np.frombuffer(r[8:72], "<u4").astype(">u4").tobytes()      # the kernel's bit buffer is MSB-first 32-bit words
         nb = (c["nbits"] + 7) // 8
         assert words[:nb] == _b(c["bits"])[:nb], ("cavlc bits", c)
+    for c in FIX["deblock"]:
+        # the kernel filters on its LDS tiles: the macroblock with 4 (luma) / 2 (chroma) samples of its left and top neighbours
+        yt = np.zeros((20, 24), np.uint8)
+        yt[:, :20] = _plane(c["y_in"], 32)[4:24, 4:24]
+        cts = []
+        for k in ("u_in", "v_in"):
+            t = np.zeros((10, 12), np.uint8)
+            t[:, :10] = _plane(c[k], 16)[2:12, 2:12]
+            cts.append(t)
+        r = run(7, yt.tobytes() + cts[0].tobytes() + cts[1].tobytes() + _b(c["bs"]), [c["qp"], c["qp_left"], c["qp_top"]], 480 + 240)
+        got_y = np.frombuffer(r[:480], np.uint8).reshape(20, 24)[:, :20]
+        assert (got_y == _plane(c["y_out"], 32)[4:24, 4:24]).all(), ("deblock luma", c["mb_type"], c["qp"], c["bs"])
+        for i, k in enumerate(("u_out", "v_out")):
+            got = np.frombuffer(r[480 + 120 * i: 600 + 120 * i], np.uint8).reshape(10, 12)[:, :10]
+            assert (got == _plane(c[k], 16)[2:12, 2:12]).all(), ("deblock chroma", c["mb_type"], c["qp"], c["bs"])
+    for c in FIX["intra4"]:
+        r = run(6, _b(c["edge"]) + bytes(3) + _b(c["in"]), [c["avail"], c["mpred"], c["penalty"]], 8 + 64)
+        mode, cost = np.frombuffer(r[:8], np.int32)
+        assert (mode, cost) == (c["mode"], c["cost"]), ("intra4", c)
+        want = np.frombuffer(_b(c["pred"]), np.uint8).reshape(4, 16)[:, :4]
+        assert (np.frombuffer(r[8:72], np.uint8).reshape(4, 16)[:, :4] == want).all(), ("intra4 prediction", c)
 
 
 def test_emulated_kernel_stages_match_reference_functions():
