@@ -297,6 +297,8 @@ __global__ void __launch_bounds__(64) h264e_nal_escape_selftest_kernel(uint8_t *
  *   3 chroma bilinear (wave_interp_chroma)     in: picture 64x64 (used as U and V)     args: x, y, w, h, dx, dy           out: 16x16: U cols 0-7, V cols 8-15
  *   4 transform/quant/dequant/recon            in: inp 256 | pred 256 | qdat 42 x u16  args: mode              out: int32 nz, dcflag | qblk_t q[16] | i16 dc[16] | i16 lev[16] | recon 256
  *   5 CAVLC block (cavlc_block)                in: int16 coef[16]                      args: first, maxn, nctx out: int32 nnz, nbits | bytes
+ *   8 motion search of one partition (diamond)  in: picture 96x96 | macroblock 16x16      args: px, py, w, h, mv x/y, pred x/y, min_sad, qp, speed, range[4], limit[4], window
+ *                                                out: int32 cost, mv x, mv y | prediction 16x16 (stride 16)
  *   7 deblock one macroblock (wave_deblock)     in: luma tile 20x24 | U tile 10x12 | V tile 10x12 | bs 32   args: qp, qp_left, qp_top   out: the three tiles
  *   6 intra 4x4 mode choice (wave_i4_choose)   in: edge 13 (L3..L0, UL, U0..U7) | block 4x4 stride 16   args: avail, mpred, penalty   out: int32 mode, cost | prediction 4x4 stride 16
  * `window` = 1 reads the reference samples through the LDS window like the macroblock loop, 0 through the HBM path.
@@ -316,12 +318,13 @@ struct StageLds
     alignas(4) uint8_t bs[32];
     alignas(4) uint8_t nb[5*24];         /* the block's neighbourhood as intra4_choose keeps it: row stride 24, block at row 1, column 4 */
 };
-#define STAGE_IN_MAX (4096 + 256 + 256)
-#define STAGE_OUT_MAX (8 + 16*64 + 32 + 32 + 256)
-DEV void stage_selftest(StageLds &S, int stage, const GLOBAL_AS uint8_t *in, const int *args, GLOBAL_AS uint8_t *out)
+#define STAGE_IN_MAX (96*96 + 256)
+#define STAGE_NARGS 24
+#define STAGE_OUT_MAX (16 + 16*64 + 32 + 32 + 256)
+DEV void stage_selftest(StageLds &S, RowLds &L, int stage, const GLOBAL_AS uint8_t *in, const int *args, GLOBAL_AS uint8_t *out)
 {
-    int a[8];
-    for (int i = 0; i < 8; i++) a[i] = uni(args[i]);
+    int a[STAGE_NARGS];
+    for (int i = 0; i < STAGE_NARGS; i++) a[i] = uni(args[i]);
     Plane P = { (const gu8 *)in, 64, 64, 64 };
     RefView R;
     R.P = P; R.win = (const lu8 *)S.win; R.has_win = 0; R.wx0 = 0; R.wy0 = 0; R.dep = 0; R.nmbx = 4; R.nmby = 4; R.vw = WIN_W; R.vh = WIN_W;
@@ -446,13 +449,34 @@ DEV void stage_selftest(StageLds &S, int stage, const GLOBAL_AS uint8_t *in, con
             for (int k = l; k < ny; k += 64) out[k] = S.yt[k];
             for (int k = l; k < nc; k += 64) { out[ny + k] = S.ctile[0][k]; out[ny + nc + k] = S.ctile[1][k]; }
         }
+    } else if (stage == 8)
+    {
+        /* the macroblock at (32,32) of a 96x96 reference picture, as row_step sets a macroblock up for inter_choose */
+        h264e_geom_t Gs;
+        MbCtx m;
+        Plane P8 = { (const gu8 *)in, 96, 96, 96 };
+        Gs.width = Gs.W = 96; Gs.height = Gs.H = 96; Gs.nmbx = Gs.nmby = 6; Gs.nmb = 36; Gs.cropping = 0;
+        Gs.lim_x0 = a[15]; Gs.lim_y0 = a[16]; Gs.lim_x1 = a[17]; Gs.lim_y1 = a[18];
+        m.G = &Gs; m.speed = a[10]; m.slice_type = 0; m.x = 2; m.y = 2; m.num = 14; m.qp = a[9];
+        m.lambda_mv = k_lambda_mv_q4[a[9]];
+        m.rv = R; m.rv.P = P8; m.rv.nmbx = 6; m.rv.nmby = 6;
+        if (a[19]) { m.rv.has_win = 1; m.rv.win = (const lu8 *)L.win; m.rv.wx0 = 32 - WIN_M; m.rv.wy0 = 32 - WIN_M; wave_load_window(L.win, P8, m.rv.wx0, m.rv.wy0, 0); }
+        WAVE_FOR(l) { lds32_store(L.inp + 4*l, gload32((const gu8 *)in + 96*96 + 4*l)); lds32_store(L.test + 4*l, 0u); }
+        wave_sync();
+        mv32 mv = mvmk(a[4], a[5]);
+        const rect_t range = { a[11], a[12], a[13], a[14] };
+        const int cost = diamond(L, m, a[0], a[1], mv, range, mvmk(a[6], a[7]), a[8], a[2], a[3], L.test + 16*a[1] + a[0]);
+        wave_sync();
+        WAVE_FOR(l) { gstore32((gu8 *)out + 16 + 4*l, lds32(L.test + 4*l)); }
+        if (wave_lane() == 0) { oi[0] = cost; oi[1] = mvx(mv); oi[2] = mvy(mv); }
     }
 }
 #ifndef H264E_EMU
 __global__ void __launch_bounds__(64) h264e_stage_selftest_kernel(int stage, const uint8_t *in, const int *args, uint8_t *out)
 {
     __shared__ StageLds S;
-    stage_selftest(S, stage, (const GLOBAL_AS uint8_t *)in, args, (GLOBAL_AS uint8_t *)out);
+    __shared__ RowLds L;
+    stage_selftest(S, L, stage, (const GLOBAL_AS uint8_t *)in, args, (GLOBAL_AS uint8_t *)out);
 }
 #endif
 
@@ -1497,17 +1521,18 @@ extern "C" int h264e_hip_selftest_nal_escape(h264e_hip_pool_t *p, const uint8_t 
 #endif
 }
 
-extern "C" int h264e_hip_selftest_stage(h264e_hip_pool_t *p, int stage, const uint8_t *in, uint32_t nin, const int *args /* [8] */, uint8_t *out, uint32_t nout)
+extern "C" int h264e_hip_selftest_stage(h264e_hip_pool_t *p, int stage, const uint8_t *in, uint32_t nin, const int *args /* [24] */, uint8_t *out, uint32_t nout)
 {
-    if (!p || !in || !args || !out || stage < 1 || stage > 7 || nin > STAGE_IN_MAX || nout > STAGE_OUT_MAX) FAIL("selftest_stage: bad argument");
+    if (!p || !in || !args || !out || stage < 1 || stage > 8 || nin > STAGE_IN_MAX || nout > STAGE_OUT_MAX) FAIL("selftest_stage: bad argument");
 #ifdef H264E_EMU
     uint8_t *bi = (uint8_t *)calloc(1, STAGE_IN_MAX + 64), *bo = (uint8_t *)calloc(1, STAGE_OUT_MAX + 64);
     StageLds *S = (StageLds *)calloc(1, sizeof(StageLds));
-    if (!bi || !bo || !S) { free(bi); free(bo); free(S); FAIL("out of host memory"); }
+    RowLds *L = (RowLds *)calloc(1, sizeof(RowLds));
+    if (!bi || !bo || !S || !L) { free(bi); free(bo); free(S); free(L); FAIL("out of host memory"); }
     memcpy(bi, in, nin);
-    stage_selftest(*S, stage, bi, args, bo);
+    stage_selftest(*S, *L, stage, bi, args, bo);
     memcpy(out, bo, nout);
-    free(bi); free(bo); free(S);
+    free(bi); free(bo); free(S); free(L);
     return 0;
 #else
     uint8_t *buf = 0;
@@ -1515,7 +1540,7 @@ extern "C" int h264e_hip_selftest_stage(h264e_hip_pool_t *p, int stage, const ui
     if (hipMalloc((void **)&buf, STAGE_IN_MAX + STAGE_OUT_MAX + 256) != hipSuccess) FAIL("selftest_stage: device allocation failed");
     hipError_t e = hipMemset(buf, 0, STAGE_IN_MAX + STAGE_OUT_MAX + 256);
     if (e == hipSuccess) e = hipMemcpy(buf, in, nin, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(buf + STAGE_IN_MAX, args, 8*sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(buf + STAGE_IN_MAX, args, STAGE_NARGS*sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess)
     {
         hipLaunchKernelGGL(h264e_stage_selftest_kernel, dim3(1), dim3(64), 0, p->stream, stage, (const uint8_t *)buf, (const int *)(buf + STAGE_IN_MAX), buf + STAGE_IN_MAX + 128);

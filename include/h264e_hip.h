@@ -157,7 +157,7 @@ int  h264e_hip_timer_stop(h264e_hip_pool_t *pool, double *ms);
 int  h264e_hip_selftest_nal_escape(h264e_hip_pool_t *pool, const uint8_t *src, uint32_t n, uint8_t *dst, uint32_t cap, uint32_t *out_n);
 /* test hook: one wave-level stage of the macroblock pipeline on caller-supplied operands (h264e_kernels.hip stage_selftest lists
  * the stages and their operand layouts; tests/test_stages.py compares them with the reference's own functions) */
-int  h264e_hip_selftest_stage(h264e_hip_pool_t *pool, int stage, const uint8_t *in, uint32_t nin, const int *args /* [8] */, uint8_t *out, uint32_t nout);
+int  h264e_hip_selftest_stage(h264e_hip_pool_t *pool, int stage, const uint8_t *in, uint32_t nin, const int *args /* [24] */, uint8_t *out, uint32_t nout);
 const char *h264e_hip_last_error(void);
 
 #ifdef __cplusplus

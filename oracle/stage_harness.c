@@ -12,6 +12,7 @@
  *   h264e_transform_add                 h264-lab.h:2638     reconstruction
  *   h264e_vlc_encode                    h264-lab.h:2775     one CAVLC residual block
  *   h264e_intra_choose_4x4              h264-lab.h:1810     intra 4x4 mode decision: nine predictors, tie-breaks, prediction
+ *   me_search_diamond + me_mv_set_range h264-lab.h:4973/5181 full-sample diamond search (SAD cache, diagonal probe) + the seven sub-sample probes
  *   df_strength + mb_deblock            h264-lab.h:5532/5642 boundary strengths of a macroblock and its in-loop filter (luma + chroma)
  *   rc_set_qp                           h264-lab.h:5839     the quantiser tables of a QP
  */
@@ -318,6 +319,78 @@ int main(void)
         printf("  }");
         first = 0;
     }
+    printf("\n ],\n");
+
+    /* ---- motion search of one partition: a 96x96 reference picture, the macroblock at (32,32) displaced by a known motion */
+    {
+        /* four reference pictures, shared by the cases */
+        static uint8_t refs[4][96*96];
+        int r4, x, y;
+        printf(" \"diamond_refs\": [\n");
+        for (r4 = 0; r4 < 4; r4++)
+        {
+            const int smooth = 3 + r4;
+            for (y = 0; y < 96; y++)
+                for (x = 0; x < 96; x++)
+                {
+                    int a = (x*smooth + y*2) % 64, b = (y*smooth - x + 960) % 48, v;
+                    a = a < 32 ? a : 63 - a; b = b < 24 ? b : 47 - b;
+                    v = 60 + 3*a + 2*b + (int)(rnd() % 5);
+                    refs[r4][y*96 + x] = (uint8_t)(v > 255 ? 255 : v);
+                }
+            printf("  {\n"); hex("pic", refs[r4], sizeof(refs[r4]), 1); printf("  }%s\n", r4 == 3 ? "" : ",");
+        }
+        printf(" ],\n");
+    printf(" \"diamond\": [\n");
+    first = 1;
+    for (i = 0; i < 64; i++)
+    {
+        const uint8_t *refp = refs[i & 3];
+        ALIGN(16) static uint8_t cur[256] ALIGN2(16), store[8*256] ALIGN2(16);
+        static const int parts[9][4] = { {0,0,16,16}, {0,0,16,8}, {0,8,16,8}, {0,0,8,16}, {8,0,8,16}, {0,0,8,8}, {8,0,8,8}, {0,8,8,8}, {8,8,8,8} };
+        const int *pt = parts[i < 16 ? 0 : i % 9], px = pt[0], py = pt[1], w = pt[2], h = pt[3];
+        const int tx = (int)(rnd() % 13) - 6, ty = (int)(rnd() % 13) - 6, qx = (int)(rnd() % 4), qy = (int)(rnd() % 4);
+        const int qp = 18 + (int)(rnd() % 24), noise = (int)(rnd() % 6);
+        point_t mv, mv_pred, wh, dd;
+        rectangle_t range;
+        pix_t *pbest = 0;
+        int ret, min_sad, sx, sy;
+        /* the input macroblock: the reference displaced by (tx + qx/4, ty + qy/4) samples, plus noise */
+        wh.u32 = 0; wh.s.x = 16; wh.s.y = 16; dd.u32 = 0; dd.s.x = (int16_t)qx; dd.s.y = (int16_t)qy;
+        h264e_qpel_interpolate_luma(refp + (32 + ty)*96 + 32 + tx, 96, cur, wh, dd);
+        for (k = 0; k < 256; k++) { int v = cur[k] + (noise ? (int)(rnd() % (unsigned)(2*noise + 1)) - noise : 0); cur[k] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+        enc->run_param.encode_speed = (i % 16 == 15) ? 9 : 0;                 /* speed 9: no sub-sample search */
+        enc->frame.mv_limit.tl = point(8*4, 8*4); enc->frame.mv_limit.br = point((96 - 16 - 8)*4, (96 - 16 - 8)*4);
+        enc->frame.mv_qpel_limit.tl = mv_add(enc->frame.mv_limit.tl, point(4*4, 4*4));
+        enc->frame.mv_qpel_limit.br = mv_add(enc->frame.mv_limit.br, point(-4*4, -4*4));
+        sx = tx + (int)(rnd() % 7) - 3; sy = ty + (int)(rnd() % 7) - 3;        /* start: near the truth, sometimes on it */
+        if (i % 5 == 0) { sx = 0; sy = 0; }
+        mv = point((32 + sx)*4, (32 + sy)*4);
+        me_mv_set_range(&mv, &range, &enc->frame.mv_limit, 32*4 + py*4);
+        mv_pred = point((32 + tx)*4 + (int)(rnd() % 17) - 8, (32 + ty)*4 + (int)(rnd() % 17) - 8);
+        wh.s.x = (int16_t)w; wh.s.y = (int16_t)h;
+        min_sad = h264e_sad_mb_unlaign_wh(refp + ((mv.s.y >> 2) + py)*96 + (mv.s.x >> 2) + px, 96, cur + py*16 + px, wh) + me_mv_cost(mv, mv_pred, qp);
+        if (i % 4 == 1) min_sad = 0x7fffff;
+        printf("%s  {\"ref\": %d, \"px\": %d, \"py\": %d, \"w\": %d, \"h\": %d, \"qp\": %d, \"speed\": %d, \"mv_in\": [%d, %d], \"mv_pred\": [%d, %d], \"min_sad_in\": %d,\n"
+               "   \"range\": [%d, %d, %d, %d], \"limit\": [%d, %d, %d, %d],\n", first ? "" : ",\n", i & 3, px, py, w, h, qp, enc->run_param.encode_speed,
+               mv.s.x, mv.s.y, mv_pred.s.x, mv_pred.s.y, min_sad, range.tl.s.x, range.tl.s.y, range.br.s.x, range.br.s.y,
+               enc->frame.mv_limit.tl.s.x, enc->frame.mv_limit.tl.s.y, enc->frame.mv_limit.br.s.x, enc->frame.mv_limit.br.s.y);
+        memset(store, 0, sizeof(store));
+        ret = me_search_diamond(enc, refp + py*96 + px, cur + py*16 + px, 96, &mv, &range, qp, mv_pred, min_sad, wh, store, &pbest,
+                                (w == 16 && h == 16) ? 256 : (w == 8 && h == 16) ? 8 : 128);
+        printf("   \"cost\": %d, \"mv\": [%d, %d],\n", ret, mv.s.x, mv.s.y);
+        {
+            uint8_t blk[256];
+            memset(blk, 0, sizeof(blk));
+            for (y = 0; y < h; y++) memcpy(blk + 16*y, pbest + 16*y, (size_t)w);
+            hex("cur", cur, 256, 0);
+            hex("pred", blk, 256, 1);
+        }
+        printf("  }");
+        first = 0;
+    }
+    }
+    enc->run_param.encode_speed = 0;
     printf("\n ]\n}\n");
     free(scratch); free(enc);
     return 0;

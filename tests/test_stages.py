@@ -179,7 +179,7 @@ def _hook(libpath):
     assert L.h264e_hip_pool_create(C.byref(pool), 0, 64, 48, 1, 1, 1) == 0
 
     def run(stage, data, args, nout):
-        a = (C.c_int * 8)(*(list(args) + [0] * (8 - len(args))))
+        a = (C.c_int * 24)(*(list(args) + [0] * (24 - len(args))))
         out = C.create_string_buffer(nout)
         assert L.h264e_hip_selftest_stage(pool, stage, data, len(data), a, out, nout) == 0, P.load().h264e_hip_last_error()
         return out.raw
@@ -221,6 +221,16 @@ def _check_stages(run):
         words = np.frombuffer(r[8:72], "<u4").astype(">u4").tobytes()      # the kernel's bit buffer is MSB-first 32-bit words
         nb = (c["nbits"] + 7) // 8
         assert words[:nb] == _b(c["bits"])[:nb], ("cavlc bits", c)
+    for window in (0, 1):
+        for c in FIX["diamond"]:
+            ref = _b(FIX["diamond_refs"][c["ref"]]["pic"])
+            args = [c["px"], c["py"], c["w"], c["h"]] + c["mv_in"] + c["mv_pred"] + [c["min_sad_in"], c["qp"], c["speed"]] + c["range"] + c["limit"] + [window]
+            r = run(8, ref + _b(c["cur"]), args, 16 + 256)
+            cost, mx, my = np.frombuffer(r[:12], np.int32)
+            assert (cost, [mx, my]) == (c["cost"], c["mv"]), ("motion search", window, {k: v for k, v in c.items() if k not in ("cur", "pred")})
+            got = np.frombuffer(r[16:272], np.uint8).reshape(16, 16)[c["py"]: c["py"] + c["h"], c["px"]: c["px"] + c["w"]]
+            want = np.frombuffer(_b(c["pred"]), np.uint8).reshape(16, 16)[: c["h"], : c["w"]]
+            assert (got == want).all(), ("motion search prediction", window, c["w"], c["h"], c["mv"])
     for c in FIX["deblock"]:
         # the kernel filters on its LDS tiles: the macroblock with 4 (luma) / 2 (chroma) samples of its left and top neighbours
         yt = np.zeros((20, 24), np.uint8)
