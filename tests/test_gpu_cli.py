@@ -4,6 +4,7 @@ import hashlib
 import json
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -95,17 +96,20 @@ def test_cli_4k_file_bounded_host_memory(app, tmp_path):
     g = GOLDEN_BIG["4k_30"]
     yuv = _synth_file(tmp_path, g["w"], g["h"], g["frames"])
     out = tmp_path / "o.264"
-    import resource
-    before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
-    r = subprocess.run([APP, "--input", str(yuv), "--output", str(out), "--clip", "1"] + g["flags"].split(),
+    # peak resident memory of THIS run only: a fresh helper process runs the app as its single child and reports the child's
+    # ru_maxrss (RUSAGE_CHILDREN of the test process itself is a maximum over every child any earlier test has waited for)
+    helper = ("import resource, subprocess, sys\n"
+              "r = subprocess.run(sys.argv[1:], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)\n"
+              "sys.stdout.write(r.stdout.decode())\n"
+              "print('MAXRSS_KB=%d RC=%d' % (resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss, r.returncode))\n")
+    r = subprocess.run([sys.executable, "-c", helper, APP, "--input", str(yuv), "--output", str(out), "--clip", "1"] + g["flags"].split(),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     text = r.stdout.decode()
-    assert r.returncode == 0, text
+    tail = [l for l in text.splitlines() if l.startswith("MAXRSS_KB=")]
+    assert r.returncode == 0 and tail and tail[-1].endswith("RC=0"), text
     assert hashlib.md5(out.read_bytes()).hexdigest() == g["md5"]
-    # ru_maxrss of RUSAGE_CHILDREN is the maximum over all children waited for so far (KB): the synth_v1 generator and the
-    # earlier CLI runs of this module are far below the bound too, so the maximum bounds this run
-    rss_kb = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
-    assert rss_kb < 2 * 1024 * 1024, (before, rss_kb, text)
+    rss_kb = int(tail[-1].split()[0].split("=")[1])
+    assert rss_kb < 2 * 1024 * 1024, (rss_kb, text)
 
 
 def test_cli_psnr_clip_mode_equals_frame_mode(app, tmp_path):
