@@ -42,14 +42,23 @@ CASES = {
     "8k_3_thr2": (7680, 4320, 3, "--qp 26 --gop 30 --threads 2", REF_THR),     # F6: the reference aborts at >= 3 slices at 8K
     "8k_3_thr2_kbps": (7680, 4320, 3, "--kbps 60000 --gop 30 --threads 2", REF_THR),   # configs[4]: multi-slice + rate control
     "1080p_20_thr8_kbps": (1920, 1080, 20, "--kbps 4000 --gop 30 --threads 8", REF_THR),
+    # tests/clips.py `scene` (numpy generator): static background, occluding sprites, a scene cut at frame 45 whose P frame is mostly intra
+    "scene_1080p_90": (1920, 1080, 90, "--qp 28 --gop 30", REF, "scene"),
+    "scene_1080p_60_thr4": (1920, 1080, 60, "--qp 30 --gop 30 --threads 4", REF_THR, "scene"),
 }
 
 
 def run_case(name, tmp):
-    w, h, n, flags, binary = CASES[name]
-    yuv = os.path.join(tmp, "sv1_%d_%dx%d.yuv" % (n, w, h))
+    w, h, n, flags, binary = CASES[name][:5]
+    clip = CASES[name][5] if len(CASES[name]) > 5 else "synth"
+    yuv = os.path.join(tmp, "%s_%d_%dx%d.yuv" % (clip, n, w, h))
     if not os.path.exists(yuv):
-        subprocess.check_call([SYNTH, str(w), str(h), str(n), yuv])
+        if clip == "synth":
+            subprocess.check_call([SYNTH, str(w), str(h), str(n), yuv])
+        else:
+            sys.path.insert(0, os.path.dirname(HERE))
+            import clips
+            clips.make(clip, w, h, n).tofile(yuv)
     o = os.path.join(tmp, "o.264")
     t0 = time.time()
     r = subprocess.run([binary, "--input", yuv, "--output", o] + flags.split() + ["--stats", "x"], capture_output=True, text=True, check=True)
@@ -62,7 +71,7 @@ def run_case(name, tmp):
         for blk in iter(lambda: f.read(1 << 24), b""):
             h5.update(blk)
     os.remove(yuv)
-    e = dict(clip="synth", w=w, h=h, frames=n, flags=flags, input_md5=h5.hexdigest(), bytes=len(data),
+    e = dict(clip=clip, w=w, h=h, frames=n, flags=flags, input_md5=h5.hexdigest(), bytes=len(data),
              md5=hashlib.md5(data).hexdigest(), frame_bytes=sizes, ref_seconds=round(dt, 1),
              binary=os.path.basename(binary))
     print(name, e["bytes"], e["md5"], "%.1f s" % dt, flush=True)
