@@ -14,9 +14,9 @@
  * (no host threads are involved here: the slices are wavefronts of the same kernel launch).
  * Not kept: --gen (libm-dependent synthetic input), --denoise.
  *
- * Extras (new option names, also argv-consuming): --device N; --clip 1 streams the file through the clip encoder (H264E_clip_*:
- * consecutive frames as a temporal wavefront on the GPU, same bitstream, bounded host memory whatever the file size; --kbps,
- * --threads, --psnr, --stats work there too); --chains N bounds the frames in flight per launch; --gpus N cuts the file into N
+ * Extras (new option names, also argv-consuming): --device N; --clip 1 (THE DEFAULT) streams the file through the clip encoder
+ * (H264E_clip_*: consecutive frames as a temporal wavefront on the GPU, same bitstream, bounded host memory whatever the file size;
+ * --kbps, --threads, --psnr, --stats work there too), --clip 0 runs the reference's own loop over H264E_encode, one frame per call; --chains N bounds the frames in flight per launch; --gpus N cuts the file into N
  * GOP-aligned blocks, one clip encoder per block and GPU, with the mv_clusters state handed over and validated at every boundary.
  */
 #define _FILE_OFFSET_BITS 64
@@ -59,7 +59,7 @@ static void parse_long(const char *p, const char *val)
 static int read_cmdline(int argc, char **argv)
 {
     int i;
-    cmd.gop = 20; cmd.qp = 33; cmd.max_frames = 99999; cmd.device = -1;
+    cmd.gop = 20; cmd.qp = 33; cmd.max_frames = 99999; cmd.device = -1; cmd.clip = -1;
     for (i = 1; i < argc; i++)
     {
         const char *p = argv[i];
@@ -87,7 +87,7 @@ static int read_cmdline(int argc, char **argv)
                "    4sif cif sif pal ntsc d1 16cif 16sif 720p 4SVGA 4XGA 16VGA 16VGA\n"
                "Options (every --option takes a value):\n"
                "    --input,  -i <f>  --output, -o <f>  --gop <n>  --qp <n>  --kbps <n>  --maxframes <n>\n"
-               "    --speed <n>  --threads <n>  --stats x  --psnr x  --device <n>  --clip 1  --chains <n>  --gpus <n>\n");
+               "    --speed <n>  --threads <n>  --stats x  --psnr x  --device <n>  --clip 0|1  --chains <n>  --gpus <n>\n");
         return 0;
     }
     return 1;
@@ -498,7 +498,9 @@ int main(int argc, char **argv)
     if (error) { printf("H264E_init error = %d\n", error); return 0; }
     printf("sizeof_persist = %d sizeof_scratch = %d\n", sizeof_persist, sizeof_scratch);
 
-    if (cmd.clip || cmd.gpus > 1)
+    /* the file goes through the streaming clip encoder unless --clip 0 asks for the reference's frame-at-a-time loop (same bytes,
+     * one pipeline latency per frame) */
+    if ((cmd.clip != 0 && cmd.max_frames) || cmd.gpus > 1)
     {
         long long total;
         int r;

@@ -49,7 +49,7 @@ def test_psnr_line_equals_reference(tmp_path):
     ref = subprocess.run([oracle_lib.REF_APP, "--input", str(yuv), "--output", str(tmp_path / "r.264")] + flags, capture_output=True, text=True)
     line = [l for l in ref.stdout.splitlines() if "YPSNR" in l]
     assert len(line) == 1
-    for extra in ([], ["--clip", "1"]):
+    for extra in (["--clip", "0"], ["--clip", "1"], []):           # the frame-at-a-time loop, the clip encoder, the default (= clip)
         r = subprocess.run([APP, "--input", str(yuv), "--output", str(tmp_path / "o.264")] + flags + extra, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         assert [l for l in r.stdout.splitlines() if "YPSNR" in l] == line

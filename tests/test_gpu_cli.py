@@ -35,12 +35,13 @@ def test_cli_matches_golden(app, tmp_path, g):
     yuv = tmp_path / ("clip_%dx%d.yuv" % (g["w"], g["h"]))
     yuv.write_bytes(c.tobytes())
     out = tmp_path / "o.264"
-    r = _run(["--input", str(yuv), "--output", str(out)] + g["flags"].split() + ["--stats", "x"], str(tmp_path))
-    text = r.stdout.decode()
-    assert r.returncode == 0, text
-    assert "sizeof_persist = 369840 sizeof_scratch = 239743" in text           # H264E_sizeof of the reference for CIF
-    assert ["frame=%d, bytes=%d" % (i, b) for i, b in enumerate(g["frame_bytes"])] == [l for l in text.splitlines() if l.startswith("frame=")]
-    assert hashlib.md5(out.read_bytes()).hexdigest() == g["md5"]
+    for mode in ([], ["--clip", "0"]):           # the default (the streaming clip encoder) and the reference's loop over H264E_encode
+        r = _run(["--input", str(yuv), "--output", str(out)] + g["flags"].split() + mode + ["--stats", "x"], str(tmp_path))
+        text = r.stdout.decode()
+        assert r.returncode == 0, text
+        assert "sizeof_persist = 369840 sizeof_scratch = 239743" in text           # H264E_sizeof of the reference for CIF
+        assert ["frame=%d, bytes=%d" % (i, b) for i, b in enumerate(g["frame_bytes"])] == [l for l in text.splitlines() if l.startswith("frame=")]
+        assert hashlib.md5(out.read_bytes()).hexdigest() == g["md5"]
 
 
 def test_cli_clip_mode_and_quirks(app, tmp_path):
@@ -120,7 +121,7 @@ def test_cli_psnr_clip_mode_equals_frame_mode(app, tmp_path):
     yuv = tmp_path / ("clip_%dx%d.yuv" % (g["w"], g["h"]))
     yuv.write_bytes(c.tobytes())
     lines = []
-    for extra in ([], ["--clip", "1"]):
+    for extra in (["--clip", "0"], ["--clip", "1"], []):           # the frame-at-a-time loop, the clip encoder, the default (= clip)
         r = _run(["--input", str(yuv), "--output", str(tmp_path / "o.264")] + g["flags"].split() + ["--psnr", "x"] + extra, str(tmp_path))
         assert r.returncode == 0, r.stdout.decode()
         lines.append([l for l in r.stdout.decode().splitlines() if "YPSNR" in l])
