@@ -552,6 +552,7 @@ static void host_free(void *p) { if (p) (void)hipHostFree(p); }
 #endif
 
 #define TASK_RING 128
+static int imin_h(int a, int b) { return a < b ? a : b; }
 
 /* One launch at a time per device, process-wide.  The macroblock kernel's forward-progress argument (every workgroup waits for
  * workgroups dispatched before it, which are resident or finished) assumes the launch has the device's wave slots to itself: two
@@ -788,22 +789,59 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     }
     {
         /* dispatch order: (job, row) sorted by the step at which the row can start when consecutive jobs are consecutive
-         * frames of one stream; every workgroup still only waits for workgroups that precede it in this order */
+         * frames of one stream; every workgroup still only waits for workgroups that precede it in this order.
+         * H264E_XCD_BANDS=1 (experiment): workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md: blocks b and b+8 share
+         * one), so the order is additionally arranged so that a macroblock row lands on the XCD of its band of rows (row*8/nmby): the
+         * rows whose reference windows overlap then share an L2. */
         const int rows = G.nmby + 1, total = nchains*rows;
-        uint32_t *ord = (uint32_t *)malloc(sizeof(uint32_t)*2*(size_t)total);
+        const int bands = getenv("H264E_XCD_BANDS") ? atoi(getenv("H264E_XCD_BANDS")) : 0;
+        uint32_t *ord = (uint32_t *)malloc(sizeof(uint32_t)*2*(size_t)total), *tmp = (uint32_t *)malloc(sizeof(uint32_t)*(size_t)total);
         int n = 0;
-        if (!ord) { h264e_hip_pool_destroy(p); FAIL("out of host memory"); }
+        if (!ord || !tmp) { free(ord); free(tmp); h264e_hip_pool_destroy(p); FAIL("out of host memory"); }
         for (int mode = 0; mode < 2; mode++)
         {
             const int lag = mode ? H264E_NARROW_FRAME_LAG : H264E_FRAME_LAG, maxkey = lag*(nchains - 1) + 2*(rows - 1);
+            int m = 0;
             for (int key = 0; key <= maxkey; key++)
                 for (int job = 0; job < nchains; job++)
                 {
                     const int r2 = key - lag*job;
                     if (r2 < 0 || (r2 & 1) || (r2 >> 1) >= rows) continue;
-                    ord[n++] = ((uint32_t)job << 16) | (uint32_t)(r2 >> 1);
+                    tmp[m++] = ((uint32_t)job << 16) | (uint32_t)(r2 >> 1);
                 }
+            if (!bands) { memcpy(ord + n, tmp, sizeof(uint32_t)*(size_t)m); n += m; continue; }
+            /* eight queues in key order, one per XCD; slot i takes the head of queue i % 8 (or, when that one has run dry, the head
+             * with the smallest key) */
+            {
+                int head[8], cnt[8] = { 0 };
+                uint32_t *q = (uint32_t *)malloc(sizeof(uint32_t)*8*(size_t)m);
+                if (!q) { free(ord); free(tmp); h264e_hip_pool_destroy(p); FAIL("out of host memory"); }
+                for (int i = 0; i < m; i++)
+                {
+                    const int row = (int)(tmp[i] & 0xffffu), x = (row >= G.nmby ? bands - 1 : imin_h(bands - 1, row*bands/G.nmby)) & 7;      /* band b -> XCD b % 8 */
+                    q[(size_t)x*m + cnt[x]++] = tmp[i];
+                }
+                for (int x = 0; x < 8; x++) head[x] = 0;
+                for (int i = 0; i < m; i++)
+                {
+                    int x = i & 7;
+                    if (head[x] >= cnt[x])
+                    {
+                        long best = -1; x = -1;
+                        for (int y = 0; y < 8; y++)
+                            if (head[y] < cnt[y])
+                            {
+                                const uint32_t jr2 = q[(size_t)y*m + head[y]];
+                                const long key = (long)lag*(long)(jr2 >> 16) + 2*(long)(jr2 & 0xffffu);
+                                if (x < 0 || key < best) { best = key; x = y; }
+                            }
+                    }
+                    ord[n++] = q[(size_t)x*m + head[x]++];
+                }
+                free(q);
+            }
         }
+        free(tmp);
         const hipError_t e = (n == 2*total) ? hipMemcpy(p->order, ord, sizeof(uint32_t)*2*(size_t)total, hipMemcpyHostToDevice) : hipErrorUnknown;
         free(ord);
         if (e != hipSuccess) { h264e_hip_pool_destroy(p); FAIL("dispatch order upload failed"); }
