@@ -810,6 +810,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
                     tmp[m++] = ((uint32_t)job << 16) | (uint32_t)(r2 >> 1);
                 }
             if (!bands) { memcpy(ord + n, tmp, sizeof(uint32_t)*(size_t)m); n += m; continue; }
+
             /* eight queues in key order, one per XCD; slot i takes the head of queue i % 8 (or, when that one has run dry, the head
              * with the smallest key) */
             {
