@@ -213,3 +213,20 @@ def test_per_macroblock_trace_matches_oracle():
             if typ < 5:
                 assert (gx, gy) == (mvx, mvy), "frame %d macroblock %d: mv (%d,%d), oracle (%d,%d)" % (t, i, gx, gy, mvx, mvy)
     ce.close()
+
+
+import sweep_cases
+
+
+@pytest.mark.parametrize("name,w,h,n,kw", sweep_cases.cases(24, 20261004, 176 * 144 * 6), ids=lambda v: str(v) if not isinstance(v, dict) else "-".join("%s%d" % (k[0], x) for k, x in v.items()))
+def test_random_configurations_match_oracle(name, w, h, n, kw):
+    """seeded sweep over sizes (cropped ones too), content, QP, GOP, speed, slices and rate control: the emulated kernels through the
+    clip encoder against the oracle"""
+    P = pkg.load_pkg()
+    c = clips.make(name, w, h, n)
+    want, sizes = oracle_lib.encode_clip(c, w, h, **kw)
+    ce = P.ClipEncoder(w, h, n, lib=pkg.EMU_LIB, **kw)
+    ce.upload(c)
+    out, fs, _ = ce.encode()
+    ce.close()
+    assert fs == sizes and out == want

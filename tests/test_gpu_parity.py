@@ -314,3 +314,23 @@ def test_per_macroblock_trace_matches_oracle(P):
             if typ < 5:
                 assert (gx, gy) == (mvx, mvy), "frame %d macroblock %d: mv (%d,%d), oracle (%d,%d)" % (t, i, gx, gy, mvx, mvy)
     ce.close()
+
+
+import sweep_cases
+
+
+@pytest.mark.parametrize("name,w,h,n,kw", sweep_cases.cases(60, 20261005, 704 * 576 * 6), ids=lambda v: str(v) if not isinstance(v, dict) else "-".join("%s%d" % (k[0], x) for k, x in v.items()))
+def test_random_configurations_match_oracle(P, name, w, h, n, kw):
+    """seeded sweep over sizes (cropped ones too), content, QP, GOP, speed, slices and rate control: clip encoder and frame-at-a-time
+    API against the oracle"""
+    c = clips.make(name, w, h, n)
+    want, sizes = oracle_lib.encode_clip(c, w, h, **kw)
+    ce = P.ClipEncoder(w, h, n, **kw)
+    ce.upload(c)
+    out, fs, _ = ce.encode()
+    ce.close()
+    assert fs == sizes and out == want
+    e = P.Encoder(w, h, **kw)
+    parts = [e.encode(c[t]) for t in range(n)]
+    e.close()
+    assert b"".join(parts) == want
