@@ -726,6 +726,7 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
 
     if (m.type != -1)
     {
+        PTIC();
         if (m.type != 5)
         {
             unsigned mask = wave_xform_quant(L.inp, L.pred, i16 ? QMODE_I16 : QMODE_INTER, L.qy, L.dcy, L.qdat[0]);
@@ -745,6 +746,7 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
             }
             wave_sync();
         }
+        PTOC(L, 30);
         if (m.nz_mask & 0xCC00) cbpl |= 1;
         if (m.nz_mask & 0x3300) cbpl |= 2;
         if (m.nz_mask & 0x00CC) cbpl |= 4;

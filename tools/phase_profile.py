@@ -41,6 +41,8 @@ def main():
               (t[18] / nmb, t[19] / t[18], t[17] / t[18], t[16] / max(t[17], 1), t[23] / t[18]))
         if t[15]:
             print("diamond: entry..end of the full-pel search %.0f cycles per call (incl. batches and the diagonal probe)" % (t[15] / t[18]))
+    if t[30]:
+        print("mb_write: luma transform + quantiser + reconstruction %.0f cycles/MB (of the mb_write line above; the CAVLC of the residual blocks measured 2.3 k)" % (t[30] / nmb))
     if t[29]:
         print("effective shader clock over the rows' lifetimes: %.0f MHz (cycle counter / 100 MHz wall clock)" % (100.0 * t[28] / t[29]))
     if t[24] or t[25]:
