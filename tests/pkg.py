@@ -18,5 +18,6 @@ def load_pkg():
     return mod
 
 
-EMU_LIB = os.path.join(ROOT, "tests", "emu", "build", "libh264e_emu.so")
+# H264E_EMU_LIB_OVERRIDE: run the emulation tests against another build of the same sources (tools/sanitize_cpu.sh: ASan + UBSan)
+EMU_LIB = os.environ.get("H264E_EMU_LIB_OVERRIDE") or os.path.join(ROOT, "tests", "emu", "build", "libh264e_emu.so")
 EMU_REV_LIB = os.path.join(ROOT, "tests", "emu", "build", "libh264e_emu_rev.so")
