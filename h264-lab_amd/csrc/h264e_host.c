@@ -814,6 +814,7 @@ struct H264E_clip_tag
     int narrow;                             /* reference-window geometry in use (h264e_dev.h) */
     int narrow_ok;                          /* the picture size allows the narrow geometry at all */
     int wide_until, wide_hold;              /* wide geometry until this frame; length of the next wide spell (doubles when narrow fails again) */
+    int launch_base, launch_frames;         /* frames per launch: the pipeline depth after a mis-speculation, growing after clean launches (H264E_clip_open) */
     long long far_acc; int far_frames;      /* far reads / frames since the last decision */
     rc_t rcs; int rc_frame, rc_qp;          /* rate control: state, the frame rc_frame_start has run for, its QP */
     /* keep_records: what every accepted frame consumed, so that a different start state can be validated later (GOP shards) */
@@ -846,6 +847,7 @@ void H264E_clip_rewind(H264E_clip_t *c)
      * pictures already fill the GPU's resident workgroups with the wide geometry: the narrow one only pays below ~12k macroblocks */
     c->narrow_ok = c->narrow = (getenv("H264E_WIDE_WINDOW") || c->seq.nmb > 12000) ? 0 : 1;
     c->wide_until = 0; c->wide_hold = 30; c->far_acc = 0; c->far_frames = 0;
+    c->launch_frames = c->ring - 1;         /* optimistic: as long as memory allows until the first mis-speculation */
     memset(&c->rcs, 0, sizeof(c->rcs));
     c->rc_frame = -1; c->rc_qp = c->par.qp;
 }
@@ -871,10 +873,29 @@ int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nfram
         /* large pictures: the ~2000 resident workgroups hold only a few frames (4K 33, 8K 16 at one workgroup per row), so slots
          * beyond that only cost memory: at most 6500 rows' worth */
         /* (row-band slices: relaunches are rare and every frame offers several wavefronts, twice as many slots pay) */
-        c->ring = par->max_chains > 0 ? par->max_chains + 1 : imax(imin(97, imax(13, (par->slices > 1 ? 13000 : 6500)/imax(c->seq.nmby, 1) + 1)), imin(1025, 97*8160/imax(nmb, 1)));
+        /* (measured: 1080p 160 frames per launch after an event beat 96 by 2.5 %, 4K 96 beat 49 by 3 %; 8K is bound by the resident
+         * workgroups, 25 frames beat 49 by 8 %) */
+        const int rows_budget = (par->slices > 1 || c->seq.nmby <= 135) ? 13000 : 6500;
+        c->launch_base = par->max_chains > 0 ? par->max_chains : imax(imin(161, imax(13, rows_budget/imax(c->seq.nmby, 1) + 1)), imin(1025, 97*8160/imax(nmb, 1))) - 1;
+        /* That is the pipeline's depth: what a launch needs to keep the chip busy, and what a launch gets right after a
+         * mis-speculation (everything behind the failed frame is thrown away, so a short launch wastes less set-up and drain).
+         * But a launch BOUNDARY without an event costs a pipeline drain and refill too (one frame latency), so event-free stretches
+         * -- row-band slices, all-intra streams, quiet content -- want launches as long as memory allows: the ring is sized by a
+         * memory budget (768 MB of host-mapped mirrors, 16 GB of HBM) and the frames per launch grow again after every clean launch
+         * (measured at 1080p x 600: 8 slices 14.5 -> 18.3 M MB/s, all-intra 14.2 -> 19.6 M, single slice 6.77 -> 6.94 M). */
+        {
+            const double host_slot = (double)nmb*168.0 + 65536.0 + 4096.0;
+            const double dev_slot = (double)nmb*256.0*3.0 + (double)nmb*(64 + 96 + 8 + 640 + 660 + 2048 + 64) + 65536.0;      /* two pictures, records, row bit buffers (2 KB per macroblock), arenas */
+            const double by_host = 768.0*1048576.0/host_slot, by_dev = 16.0*1073741824.0/dev_slot;
+            int cap = (int)(by_host < by_dev ? by_host : by_dev);
+            cap = imin(imax(cap, c->launch_base), 1024);
+            c->ring = (par->max_chains > 0 ? par->max_chains : cap) + 1;
+        }
     }
-    if (getenv("H264E_RING")) c->ring = atoi(getenv("H264E_RING"));       /* experiments */
+    if (getenv("H264E_RING")) { c->ring = atoi(getenv("H264E_RING")); c->launch_base = imin(c->launch_base, imax(c->ring - 1, 1)); }      /* experiments */
     c->ring = imax(2, imin(c->ring, nframes + 1));
+    if (getenv("H264E_LAUNCH_BASE")) c->launch_base = atoi(getenv("H264E_LAUNCH_BASE"));      /* experiments */
+    c->launch_base = imax(1, imin(c->launch_base, c->ring - 1));
     c->resident = par->resident_frames > 0 ? imin(par->resident_frames, nframes) : nframes;
     c->traj = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)c->seq.nmb);
     c->tasks = (h264e_hip_task_t *)calloc((size_t)c->ring, sizeof(*c->tasks));
@@ -1080,7 +1101,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
     {
         const int n = c->next, limit = c->avail;       /* frames uploaded from the idle hook during this launch join the next one */
         /* with --psnr style statistics every frame's picture must still be in its slot when the launch has drained */
-        const int F = rc_on ? 1 : imin(K - 1, limit - n);
+        const int F = rc_on ? 1 : imin(imin(K - 1, c->launch_frames), limit - n);
         int nvalid = 0;
         t0 = now_ms();
         memset(tasks, 0, sizeof(*tasks)*(size_t)K);
@@ -1217,6 +1238,10 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             if (h264e_hip_ssd_frames(c->pool, nvalid, n % c->resident, c->resident, n % K, K, c->ssd_out + 3*(size_t)(n - first))) goto done;
         }
         c->next = n + nvalid;
+        /* frames per launch: back to the pipeline depth after a mis-speculation, twice as many after a clean launch */
+        /* (after an event: twice the frames the stopped launch got through, an estimate of the spacing of the events) */
+        if (nvalid < F && !full) c->launch_frames = imin(imax(c->launch_base, 2*nvalid), K - 1);
+        else if (nvalid == F) c->launch_frames = imin(2*c->launch_frames, K - 1);
         /* Window geometry for the next launch.  More than one macroblock in eight leaving the narrow window over at least 8 frames:
          * the wide one pays -- for a while: such motion is often a transient (a scene cut, an object wrapping around), so the narrow
          * geometry is tried again after wide_hold frames, a spell that doubles every time it fails again. */

@@ -578,7 +578,9 @@ struct h264e_hip_pool
     h264e_frame_task_t *tasks_dev;       /* ring of TASK_RING task arrays */
     int *progress_all;
     int *errflag;
-    uint32_t *order;                     /* [2][nchains*(nmby+1)] (job << 16) | row in dispatch order: wide / narrow frame lag */
+    uint32_t *order;                     /* device [nchains*(nmby+1)] (job << 16) | row in dispatch order of the current launch shape */
+    uint32_t *order_host;                /* host copy being built (build_order) */
+    int order_jobs, order_narrow;        /* the launch shape `order` holds: jobs, window geometry (-1: none yet) */
     int *stepflags;                      /* [nchains][2]: {clusters_moved, overflow} of the last step, one read per step */
     /* streaming: per chain slot, host-mapped result buffers the finalizer workgroups fill while the launch runs */
     h264e_hostdone_t *host_done;         /* [nchains] */
@@ -649,7 +651,7 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
 #endif
     device_release(p);
     host_free(p->hheap);
-    free(p->host_rbsp); free(p->host_mbrec); free(p->slot_launch);
+    free(p->host_rbsp); free(p->host_mbrec); free(p->slot_launch); free(p->order_host);
     dev_free(p->heap);
 #ifndef H264E_EMU
     if (p->stream)
@@ -663,6 +665,62 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
     free(p->chains_host); free(p->clu_dev); free(p->ref_sel); free(p->traj_dev); free(p->traj_cur);
     free(p);
 }
+
+#ifndef H264E_EMU
+/* Dispatch order of a launch of `jobs` jobs: (job, row) sorted by the step at which the row can start when consecutive jobs are
+ * consecutive frames of one stream (lag*job + 2*row: a counting sort); every workgroup still only waits for workgroups that precede it
+ * in this order (far reads: a bounded distance ahead).  Built for the number of jobs a launch really has, so that a pool with many
+ * slots does not dispatch thousands of empty workgroups with every short launch.
+ * H264E_XCD_BANDS=N (experiment, profiles/r02_xcd_bands.txt): workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md:
+ * blocks b and b+8 share one), so the order is additionally arranged so that a macroblock row lands on the XCD of its band of rows
+ * (row*N/nmby mod 8): the rows whose reference windows overlap then share an L2. */
+static int build_order(h264e_hip_pool_t *p, int jobs, int narrow)
+{
+    const h264e_geom_t &G = p->G;
+    const int rows = G.nmby + 1, total = jobs*rows, lag = narrow ? H264E_NARROW_FRAME_LAG : H264E_FRAME_LAG, maxkey = lag*(jobs - 1) + 2*(rows - 1);
+    const int bands = getenv("H264E_XCD_BANDS") ? atoi(getenv("H264E_XCD_BANDS")) : 0;
+    uint32_t *ord = p->order_host;
+    int *start = (int *)calloc((size_t)maxkey + 2, sizeof(int));
+    uint32_t *tmp = bands ? (uint32_t *)malloc(sizeof(uint32_t)*(size_t)total) : ord;
+    if (!start || !tmp) { free(start); if (bands) free(tmp); return -1; }
+    for (int job = 0; job < jobs; job++) for (int r = 0; r < rows; r++) start[lag*job + 2*r + 1]++;
+    for (int k = 0; k <= maxkey; k++) start[k + 1] += start[k];
+    for (int job = 0; job < jobs; job++) for (int r = 0; r < rows; r++) tmp[start[lag*job + 2*r]++] = ((uint32_t)job << 16) | (uint32_t)r;     /* ties: by job */
+    free(start);
+    if (bands)
+    {
+        /* eight queues in key order, one per XCD; slot i takes the head of queue i % 8 (or, when that one has run dry, the head with
+         * the smallest key) */
+        int head[8], cnt[8] = { 0 }, n = 0;
+        uint32_t *q = (uint32_t *)malloc(sizeof(uint32_t)*8*(size_t)total);
+        if (!q) { free(tmp); return -1; }
+        for (int i = 0; i < total; i++)
+        {
+            const int row = (int)(tmp[i] & 0xffffu), x = (row >= G.nmby ? bands - 1 : imin_h(bands - 1, row*bands/G.nmby)) & 7;      /* band b -> XCD b % 8 */
+            q[(size_t)x*total + cnt[x]++] = tmp[i];
+        }
+        for (int x = 0; x < 8; x++) head[x] = 0;
+        for (int i = 0; i < total; i++)
+        {
+            int x = i & 7;
+            if (head[x] >= cnt[x])
+            {
+                long best = -1; x = -1;
+                for (int y = 0; y < 8; y++)
+                    if (head[y] < cnt[y])
+                    {
+                        const uint32_t jr2 = q[(size_t)y*total + head[y]];
+                        const long key = (long)lag*(long)(jr2 >> 16) + 2*(long)(jr2 & 0xffffu);
+                        if (x < 0 || key < best) { best = key; x = y; }
+                    }
+            }
+            ord[n++] = q[(size_t)x*total + head[x]++];
+        }
+        free(q); free(tmp);
+    }
+    return 0;
+}
+#endif
 
 extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int width, int height, int nchains,
                                      int frames_resident, int slots)
@@ -731,7 +789,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         p->abort_dev = (int *)carve(64, 256);
         p->walkrec = (h264e_walkrec_t *)carve(sizeof(h264e_walkrec_t)*(size_t)nchains, 256);
         p->ssd_dev = (unsigned long long *)carve(sizeof(unsigned long long)*3*(size_t)nchains, 256);
-        p->order = (uint32_t *)carve(sizeof(uint32_t)*2*(size_t)nchains*(G.nmby + 1), 256);
+        p->order = (uint32_t *)carve(sizeof(uint32_t)*(size_t)nchains*(G.nmby + 1), 256);
         p->host_done = (h264e_hostdone_t *)hcarve(sizeof(h264e_hostdone_t)*(size_t)nchains);
         p->abort_word = (int *)hcarve(64);
         for (int c = 0; c < nchains; c++)
@@ -787,66 +845,9 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         h264e_hip_pool_destroy(p);
         FAIL("descriptor upload failed");
     }
-    {
-        /* dispatch order: (job, row) sorted by the step at which the row can start when consecutive jobs are consecutive
-         * frames of one stream; every workgroup still only waits for workgroups that precede it in this order.
-         * H264E_XCD_BANDS=1 (experiment): workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md: blocks b and b+8 share
-         * one), so the order is additionally arranged so that a macroblock row lands on the XCD of its band of rows (row*8/nmby): the
-         * rows whose reference windows overlap then share an L2. */
-        const int rows = G.nmby + 1, total = nchains*rows;
-        const int bands = getenv("H264E_XCD_BANDS") ? atoi(getenv("H264E_XCD_BANDS")) : 0;
-        uint32_t *ord = (uint32_t *)malloc(sizeof(uint32_t)*2*(size_t)total), *tmp = (uint32_t *)malloc(sizeof(uint32_t)*(size_t)total);
-        int n = 0;
-        if (!ord || !tmp) { free(ord); free(tmp); h264e_hip_pool_destroy(p); FAIL("out of host memory"); }
-        for (int mode = 0; mode < 2; mode++)
-        {
-            const int lag = mode ? H264E_NARROW_FRAME_LAG : H264E_FRAME_LAG, maxkey = lag*(nchains - 1) + 2*(rows - 1);
-            int m = 0;
-            for (int key = 0; key <= maxkey; key++)
-                for (int job = 0; job < nchains; job++)
-                {
-                    const int r2 = key - lag*job;
-                    if (r2 < 0 || (r2 & 1) || (r2 >> 1) >= rows) continue;
-                    tmp[m++] = ((uint32_t)job << 16) | (uint32_t)(r2 >> 1);
-                }
-            if (!bands) { memcpy(ord + n, tmp, sizeof(uint32_t)*(size_t)m); n += m; continue; }
-
-            /* eight queues in key order, one per XCD; slot i takes the head of queue i % 8 (or, when that one has run dry, the head
-             * with the smallest key) */
-            {
-                int head[8], cnt[8] = { 0 };
-                uint32_t *q = (uint32_t *)malloc(sizeof(uint32_t)*8*(size_t)m);
-                if (!q) { free(ord); free(tmp); h264e_hip_pool_destroy(p); FAIL("out of host memory"); }
-                for (int i = 0; i < m; i++)
-                {
-                    const int row = (int)(tmp[i] & 0xffffu), x = (row >= G.nmby ? bands - 1 : imin_h(bands - 1, row*bands/G.nmby)) & 7;      /* band b -> XCD b % 8 */
-                    q[(size_t)x*m + cnt[x]++] = tmp[i];
-                }
-                for (int x = 0; x < 8; x++) head[x] = 0;
-                for (int i = 0; i < m; i++)
-                {
-                    int x = i & 7;
-                    if (head[x] >= cnt[x])
-                    {
-                        long best = -1; x = -1;
-                        for (int y = 0; y < 8; y++)
-                            if (head[y] < cnt[y])
-                            {
-                                const uint32_t jr2 = q[(size_t)y*m + head[y]];
-                                const long key = (long)lag*(long)(jr2 >> 16) + 2*(long)(jr2 & 0xffffu);
-                                if (x < 0 || key < best) { best = key; x = y; }
-                            }
-                    }
-                    ord[n++] = q[(size_t)x*m + head[x]++];
-                }
-                free(q);
-            }
-        }
-        free(tmp);
-        const hipError_t e = (n == 2*total) ? hipMemcpy(p->order, ord, sizeof(uint32_t)*2*(size_t)total, hipMemcpyHostToDevice) : hipErrorUnknown;
-        free(ord);
-        if (e != hipSuccess) { h264e_hip_pool_destroy(p); FAIL("dispatch order upload failed"); }
-    }
+    p->order_host = (uint32_t *)malloc(sizeof(uint32_t)*(size_t)nchains*(G.nmby + 1));
+    if (!p->order_host) { h264e_hip_pool_destroy(p); FAIL("out of host memory"); }
+    p->order_jobs = -1;
 #endif
     *pool = p;
     return 0;
@@ -1063,7 +1064,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     if (p->pending >= TASK_RING - 1 && h264e_hip_sync(p)) return -1;
     h264e_frame_task_t *host = (h264e_frame_task_t *)calloc((size_t)p->nchains, sizeof(h264e_frame_task_t));
     if (!host) FAIL("out of host memory");
-    int any = 0, any_narrow = 0, any_wide = 0;
+    int any = 0, any_narrow = 0, any_wide = 0, njobs = 0;
     const int launch_id = ++p->launch_counter;
     for (int c = 0; c < p->nchains; c++)
     {
@@ -1077,7 +1078,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             free(host);
             FAIL("submit: bad task for chain %d", c);
         }
-        any = 1;
+        any = 1; njobs = c + 1;
         const uint8_t *f = p->clip + p->frame_bytes*(size_t)t.frame_index;
         d.in[0] = f; d.in[1] = f + (size_t)G.width*G.height; d.in[2] = d.in[1] + (size_t)(G.width/2)*(G.height/2);
         d.in_stride[0] = G.width; d.in_stride[1] = d.in_stride[2] = G.width/2;
@@ -1259,13 +1260,20 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         }
     free(host);
     if (e != hipSuccess) FAIL("progress reset: %s", hipGetErrorString(e));
+    /* the dispatch order for this launch's shape (jobs up to the last active one; window geometry) */
+    if (njobs != p->order_jobs || any_narrow != p->order_narrow)
+    {
+        if (build_order(p, njobs, any_narrow)) FAIL("out of host memory");
+        HIPCHK(hipMemcpyAsync(p->order, p->order_host, sizeof(uint32_t)*(size_t)njobs*(G.nmby + 1), hipMemcpyHostToDevice, p->stream));     /* pageable: staged before the call returns */
+        p->order_jobs = njobs; p->order_narrow = any_narrow;
+    }
     const int pe = p->ev_pending;
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][0], p->stream));
     if (any_narrow)
-        hipLaunchKernelGGL(h264e_mb_kernel<true>, dim3((unsigned)(p->nchains*(G.nmby + 1))), dim3(64), 0, p->stream,
-                           G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, (const uint32_t *)p->order + (size_t)p->nchains*(G.nmby + 1), p->errflag, p->stepflags);
+        hipLaunchKernelGGL(h264e_mb_kernel<true>, dim3((unsigned)(njobs*(G.nmby + 1))), dim3(64), 0, p->stream,
+                           G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, (const uint32_t *)p->order, p->errflag, p->stepflags);
     else
-        hipLaunchKernelGGL(h264e_mb_kernel<false>, dim3((unsigned)(p->nchains*(G.nmby + 1))), dim3(64), 0, p->stream,
+        hipLaunchKernelGGL(h264e_mb_kernel<false>, dim3((unsigned)(njobs*(G.nmby + 1))), dim3(64), 0, p->stream,
                            G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, (const uint32_t *)p->order, p->errflag, p->stepflags);
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][1], p->stream));
     HIPCHK(hipGetLastError());
