@@ -847,7 +847,9 @@ void H264E_clip_rewind(H264E_clip_t *c)
      * pictures already fill the GPU's resident workgroups with the wide geometry: the narrow one only pays below ~12k macroblocks */
     c->narrow_ok = c->narrow = (getenv("H264E_WIDE_WINDOW") || c->seq.nmb > 12000) ? 0 : 1;
     c->wide_until = 0; c->wide_hold = 30; c->far_acc = 0; c->far_frames = 0;
-    c->launch_frames = c->ring - 1;         /* optimistic: as long as memory allows until the first mis-speculation */
+    /* optimistic where mis-speculations are rare by construction (row bands restart the state, intra frames do not read it): as long
+     * as memory allows; else the pipeline depth, growing with every clean launch */
+    c->launch_frames = (c->par.slices > 1 || c->gop_len == 1) ? c->ring - 1 : c->launch_base;
     memset(&c->rcs, 0, sizeof(c->rcs));
     c->rc_frame = -1; c->rc_qp = c->par.qp;
 }
@@ -881,12 +883,12 @@ int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nfram
          * mis-speculation (everything behind the failed frame is thrown away, so a short launch wastes less set-up and drain).
          * But a launch BOUNDARY without an event costs a pipeline drain and refill too (one frame latency), so event-free stretches
          * -- row-band slices, all-intra streams, quiet content -- want launches as long as memory allows: the ring is sized by a
-         * memory budget (768 MB of host-mapped mirrors, 16 GB of HBM) and the frames per launch grow again after every clean launch
+         * memory budget (896 MB of host-mapped mirrors, 24 GB of HBM) and the frames per launch grow again after every clean launch
          * (measured at 1080p x 600: 8 slices 14.5 -> 18.3 M MB/s, all-intra 14.2 -> 19.6 M, single slice 6.77 -> 6.94 M). */
         {
             const double host_slot = (double)nmb*168.0 + 65536.0 + 4096.0;
             const double dev_slot = (double)nmb*256.0*3.0 + (double)nmb*(64 + 96 + 8 + 640 + 660 + 2048 + 64) + 65536.0;      /* two pictures, records, row bit buffers (2 KB per macroblock), arenas */
-            const double by_host = 768.0*1048576.0/host_slot, by_dev = 16.0*1073741824.0/dev_slot;
+            const double by_host = 896.0*1048576.0/host_slot, by_dev = 24.0*1073741824.0/dev_slot;
             int cap = (int)(by_host < by_dev ? by_host : by_dev);
             cap = imin(imax(cap, c->launch_base), 1024);
             c->ring = (par->max_chains > 0 ? par->max_chains : cap) + 1;
