@@ -330,7 +330,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "synthetic %dx%d YUV420 %d frames IPPP GOP %d QP %d, %s (BASELINE configs[2])" %
                                    (w, h, frames, gop, QP, "ONE stream GOP-sharded over the ranks" if stream_mode else "one clip per rank on 1xMI355X each"),
-                       "frames_per_step": frames, "frames_in_flight": st.chains if st is not None else None, "fps": total_frames / dt,
+                       "frames_per_step": frames, "slot_ring_frames": st.chains if st is not None else None, "fps": total_frames / dt,
                        "coded_bytes_per_step": len(out), "relaunches_per_step": (st.reencoded_gops if st is not None else None),
                        "slices_per_frame": max(a.slices, 1), "shard": a.shard},
             # achieved = algorithmic READ bytes (755.2 B/MB at GOP 30) / kernel time; read+write beside it
