@@ -116,7 +116,8 @@ const char *H264E_last_error(void);
 /* Whole-clip streaming encode: consecutive frames run as a temporal wavefront inside one
  * kernel launch, finished frames are validated and NAL-assembled by the host while the launch runs (DESIGN.md
  * sections 4-5).  Bit-identical to feeding the frames one by one to H264E_encode.  With rate control (kbps) a frame's QP depends on the size
- * of the frame before it, so frames cannot overlap and run one per launch. */
+ * of the frame before it: the frames behind the first one of a launch run on a speculated QP and are stopped when the exact
+ * controller disagrees. */
 typedef struct
 {
     int width, height, gop, qp, speed;
@@ -126,7 +127,7 @@ typedef struct
     int first_idr_pic_id_state;             /* enc->next_idr_pic_id before the first frame (0 for a fresh stream) */
     int32_t mv_clusters_in[2];              /* enc->mv_clusters before the first frame (0,0 for a fresh stream) */
     int slices;                             /* row-band slices per frame: 0 / 1 = one; N = the reference's H264E_MAX_THREADS build with --threads N */
-    int kbps;                               /* 0 = constant QP `qp`; > 0 = frame-level rate control as encode_app --kbps (frames then run one per launch) */
+    int kbps;                               /* 0 = constant QP `qp`; > 0 = frame-level rate control as encode_app --kbps (a few frames per launch then, on a speculated QP that is validated against the exact controller) */
     int resident_frames;                    /* input frames kept in HBM (a ring, frame f in slot f % resident_frames); 0 = the whole clip */
     int keep_records;                       /* keep what every frame consumed, for H264E_clip_revalidate (GOP shards of one stream) */
 } H264E_clip_param_t;
