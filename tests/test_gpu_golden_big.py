@@ -46,3 +46,17 @@ def test_full_length_stream_matches_reference(P, name):
     assert len(out) == g["bytes"] and hashlib.md5(out).hexdigest() == g["md5"]
     if name == "bench_1080p_600":
         assert st.reencoded_gops >= 10, "the bench stream no longer exercises the relaunch path"
+
+
+@pytest.mark.parametrize("name,max_chains", [("bench_1080p_600", 64), ("bench_1080p_600_thr8", 40), ("cif_300_gop30", 16), ("1080p_30_kbps", 3)])
+def test_full_length_stream_with_a_small_slot_ring(P, name, max_chains):
+    """the same streams with the slot ring capped far below the clip length (frame f lives in slot f mod K, so slots are reused many
+    times and every launch boundary falls somewhere else): still the reference's bytes"""
+    g = GOLDEN_BIG[name]
+    f = _flags(g["flags"])
+    ce = P.ClipEncoder(g["w"], g["h"], g["frames"], gop=f["gop"], qp=f["qp"], speed=f["speed"], slices=f["slices"], kbps=f["kbps"], max_chains=max_chains)
+    ce.generate_synth()
+    out, sizes, st = ce.encode()
+    ce.close()
+    assert sizes == g["frame_bytes"]
+    assert len(out) == g["bytes"] and hashlib.md5(out).hexdigest() == g["md5"]
