@@ -903,10 +903,17 @@ int H264E_clip_open(H264E_clip_t **out, const H264E_clip_param_t *par, int nfram
     c->traj = (int32_t *)malloc(sizeof(int32_t)*2*(size_t)c->seq.nmb);
     c->tasks = (h264e_hip_task_t *)calloc((size_t)c->ring, sizeof(*c->tasks));
     c->used = (int32_t (*)[2])calloc((size_t)c->ring, sizeof(int32_t[2]));
-    if (!c->traj || !c->tasks || !c->used || h264e_hip_pool_create(&c->pool, par->device, par->width, par->height, c->ring, c->resident, 1))
+    if (!c->traj || !c->tasks || !c->used) { free(c->traj); free(c->tasks); free(c->used); free(c); return -1; }
+    /* the ring is sized for speed, not for need: when the device (or the pinned host memory) cannot spare that much, halve it down
+     * to the pipeline depth before giving up */
+    while (h264e_hip_pool_create(&c->pool, par->device, par->width, par->height, c->ring, c->resident, 1))
     {
-        free(c->traj); free(c->tasks); free(c->used); free(c);
-        return -1;
+        if (c->ring <= c->launch_base + 1 || par->max_chains > 0)
+        {
+            free(c->traj); free(c->tasks); free(c->used); free(c);
+            return -1;
+        }
+        c->ring = imax(c->launch_base + 1, c->ring/2);
     }
     if (par->keep_records)
     {
