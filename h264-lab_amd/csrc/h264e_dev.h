@@ -179,6 +179,7 @@ typedef struct
     const int *abort_word;              /* device memory, or NULL: the job stops once *abort_word == launch_id (raised by a finalizer whose walk
                                            failed, or by the host) */
     int walk_on_device;                 /* the finalizer validates the mv_clusters speculation itself */
+    int walk_quiet;                     /* a failed walk of this job does not raise the launch's abort word (a leaf nobody depends on) */
     mv32 exact_state[2];                /* ... from this exact state when walk_prev is NULL (first job of the launch) */
     const h264e_walkrec_t *walk_prev;   /* ... else from the verdict of the job before it in stream order (same launch) */
     h264e_walkrec_t *walk_out;          /* this job's verdict */

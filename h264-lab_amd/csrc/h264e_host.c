@@ -1167,17 +1167,47 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             t->first_row = (i == 0 && c->first_dev) ? c->first_row : 0;
             t->narrow_window = c->narrow;
         }
+        /* Hedges (rate control): the speculated QP of a frame is usually off by one or two when it is off, so every frame behind the
+         * first one is ALSO encoded with the neighbouring QPs, as leaves in spare slots (same reference, same mv_clusters
+         * speculation; the chip is nearly empty in this mode).  When the chain breaks at a frame, the leaf with the exact QP -- if
+         * there is one -- is the frame; its picture then moves to the slot the frame number owns and the launch ends there. */
+        int nh = 0, hedge_level[32], hedge_qp[32];
+        if (rc_on && F > 1)
+        {
+            static const int dq[4] = { -1, 1, -2, 2 };
+            const int rc_hedge = imax(0, imin(4, getenv("H264E_RC_HEDGE") ? atoi(getenv("H264E_RC_HEDGE")) : (nmb >= 60000 ? 0 : nmb >= 20000 ? 2 : 4)));      /* measured: 8K is bound by the resident workgroups, leaves only cost there */
+            int k, a;
+            for (k = 1; k < F; k++)
+                for (a = 0; a < rc_hedge; a++)
+                {
+                    const int q = qp_task[k & 7] + dq[a], f = n + k, key = (f % G) == 0, j = F + nh;
+                    h264e_hip_task_t *t = tasks + j;
+                    uint16_t qd[2][42];
+                    if (q < qp_min || q > qp_max || nh >= 32 || j + 2 >= K) continue;
+                    *t = tasks[k];
+                    build_qdat(qd, q, !key);
+                    t->qp = q;
+                    memcpy(t->qdat, qd, sizeof(t->qdat));
+                    slice_header_bits(&c->seq, key, f % G, (idr_state ^ ((f/G + 1) & 1)), q, pic_init_qp, no_deblock, nslices, &t->hdr_nal, &t->hdr_bits, &t->hdr_nbits);
+                    t->slot = (n + j) % K;              /* a slot no frame of this launch owns */
+                    t->walk_parent = k;                 /* = index of the chain's frame in front of it, + 1 */
+                    t->walk_quiet = 1;                  /* its own validation failing stops nobody else */
+                    used[j][0] = used[k][0]; used[j][1] = used[k][1];
+                    hedge_level[nh] = k; hedge_qp[nh] = q; nh++;
+                }
+        }
         stats.rounds++;
         c->have_after = 0;
         const double t_submit = now_ms();
         double t_first = 0, t_last = 0;
-        int rc_miss = 0;
+        int rc_miss = 0, take = -1, moved_from = -1, moved_to = -1;
         if (h264e_hip_submit(c->pool, tasks)) goto done;
 
         /* consume the frames in stream order while the launch is still running */
-        for (i = 0; i < F; i++)
+        for (i = 0; i < F || take >= 0; i++)
         {
-            const int f = n + i, key = (f % G) == 0, slot = f % K, per_mb = (i == 0 && c->first_dev);
+            const int is_hedge = take >= 0, ti = is_hedge ? take : i;
+            const int f = is_hedge ? n + hedge_level[take - F] : n + i, key = (f % G) == 0, slot = tasks[ti].slot, per_mb = (ti == 0 && c->first_dev);
             h264e_hip_result_t r1;
             int dn, idle = 0;
             int32_t cc[2];
@@ -1188,7 +1218,16 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
                 if (c->idle_hook) c->idle_hook(c->idle_token);
                 sched_yield();
             }
+            take = -1;
             if (dn == 0) dn = h264e_hip_stream_done(c->pool, slot, &r1);
+            if (is_hedge && dn != 1)
+            {
+                /* the leaf did not make it (its own mv_clusters validation failed, or the launch was stopped): the frame is simply
+                 * encoded in the next launch */
+                if (dn < 0) goto done;
+                if (h264e_hip_stream_abort(c->pool)) goto done;
+                break;
+            }
             if (dn == 2 && r1.walk_status == 2)
             {
                 /* the device's exact walk found a macroblock of this frame that consumed other rounded candidates than the exact
@@ -1247,8 +1286,14 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
                         const int nkey = ((f + 1) % G) == 0;
                         qp = c->rc_qp = rc_frame_start(&c->rcs, c->par.gop, nmb, c->par.vbv_size_bytes, desired_frame_bytes, qp_min, qp_max, nkey);
                         c->rc_frame = f + 1;
-                        if (i + 1 < F && qp_task[(i + 1) & 7] != qp) rc_miss = 1;
-                    }
+                        if (is_hedge) rc_miss = 1;                  /* a leaf has nothing behind it */
+                        else if (i + 1 < F && qp_task[(i + 1) & 7] != qp)
+                        {
+                            int hh;
+                            rc_miss = 1;
+                            for (hh = 0; hh < nh; hh++) if (hedge_level[hh] == i + 1 && hedge_qp[hh] == qp) { take = F + hh; rc_miss = 0; }
+                        }
+                    } else if (is_hedge) rc_miss = 1;
                 }
             }
             if (c->rec_store)
@@ -1258,7 +1303,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
                 if (!c->rec_store[f]) c->rec_store[f] = (h264e_hip_mbrec_t *)malloc(rb);
                 if (!c->rec_store[f]) goto done;
                 memcpy(c->rec_store[f], h264e_hip_stream_mbrec(c->pool, slot), rb);
-                c->used_store[f][0] = used[i][0]; c->used_store[f][1] = used[i][1];
+                c->used_store[f][0] = used[ti][0]; c->used_store[f][1] = used[ti][1];
                 free(c->permb_store[f]); c->permb_store[f] = NULL;
                 if (per_mb)
                 {
@@ -1267,17 +1312,20 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
                 }
             }
             c->state[0] = cc[0]; c->state[1] = cc[1];
-            if (i == 0) c->first_dev = 0;
+            if (ti == 0) c->first_dev = 0;
             stats.assemble_ms += now_ms() - t0;
             nvalid++;
+            if (is_hedge) { moved_from = slot; moved_to = f % K; }
             if (rc_miss)
             {
                 if (h264e_hip_stream_abort(c->pool)) goto done;
                 stats.reencoded_gops++;
                 break;
             }
+            if (take >= 0) i = F - 1;           /* the chain ends here: one more round, for the leaf */
         }
         if (h264e_hip_sync(c->pool)) goto done;         /* the launch has drained (immediately after an abort) */
+        if (moved_from >= 0 && h264e_hip_stream_copy_picture(c->pool, moved_from, moved_to)) goto done;
         stats.encode_ms += now_ms() - t_submit;
         if (c->ssd_out && nvalid)
         {

@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
             {
                 if (threadIdx.x == 0)
                 {
-                    if (wstatus == H264E_WALK_BAD && T.abort_word)
+                    if (wstatus == H264E_WALK_BAD && T.abort_word && !T.walk_quiet)
                         __hip_atomic_store((GLOBAL_AS int *)T.abort_word, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (hd)
                     {
@@ -1106,9 +1106,13 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
                 if (t.walk_on_device && p->traj_dev[t.slot])
                 {
                     d.walk_on_device = 1;
+                    d.walk_quiet = t.walk_quiet;
                     d.exact_state[0] = t.exact_state[0]; d.exact_state[1] = t.exact_state[1];
                     d.walk_out = p->walkrec + t.slot;
-                    d.walk_prev = (c > 0 && tasks[c - 1].active && tasks[c - 1].stream_mode && tasks[c - 1].walk_on_device) ? p->walkrec + tasks[c - 1].slot : 0;
+                    {
+                        const int par = t.walk_parent > 0 ? t.walk_parent - 1 : c - 1;
+                        d.walk_prev = (par >= 0 && par < c && tasks[par].active && tasks[par].stream_mode && tasks[par].walk_on_device) ? p->walkrec + tasks[par].slot : 0;
+                    }
                     d.traj_out = p->traj_dev[t.slot] + (size_t)(p->traj_cur[t.slot] ^ 1)*2*G.nmb;
                 }
             }
@@ -1329,6 +1333,21 @@ extern "C" int h264e_hip_stream_fetch_traj(h264e_hip_pool_t *p, int slot, int co
 #else
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipMemcpy(dst, src, sizeof(int32_t)*2*(size_t)p->G.nmb, hipMemcpyDeviceToHost));
+#endif
+    return 0;
+}
+
+extern "C" int h264e_hip_stream_copy_picture(h264e_hip_pool_t *p, int from, int to)
+{
+    if (!p || from < 0 || to < 0 || from >= p->nchains || to >= p->nchains) FAIL("stream_copy_picture: bad argument");
+    if (from == to) return 0;
+    const size_t plane = (size_t)p->G.W*p->G.H*3/2;
+#ifdef H264E_EMU
+    memcpy(p->chains_host[to].rec[0][0], p->chains_host[from].rec[0][0], plane);
+#else
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpyAsync(p->chains_host[to].rec[0][0], p->chains_host[from].rec[0][0], plane, hipMemcpyDeviceToDevice, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
 #endif
     return 0;
 }

@@ -52,6 +52,10 @@ typedef struct
     /* stream mode: encode this frame again from macroblock row first_row; the rows above it (bits, records, picture) are
      * kept from the previous encode of the same frame in the same slot (0 = whole frame) */
     int first_row;
+    /* stream mode, device walk: index + 1 of the task whose verdict this frame's walk starts from; 0 = the task in front of it */
+    int walk_parent;
+    /* ... and a frame whose failed validation concerns nobody but itself (a leaf): it reports the verdict but does not stop the launch */
+    int walk_quiet;
     /* stream mode: the job's finalizer validates the mv_clusters speculation ON THE DEVICE (exact walk over the frame's records,
      * enc_row.h device_clusters_walk): task 0 of a submit starts from exact_state, task i from the verdict of task i-1; a mismatch
      * stops the launch (device abort word) and is reported in the result (walk_status, first_bad, state_out); the walked
@@ -119,6 +123,9 @@ const h264e_hip_mbrec_t *h264e_hip_stream_mbrec(h264e_hip_pool_t *pool, int slot
  * traj_from_device will consume), 1 the one its last encode consumed (traj_from_device) */
 int  h264e_hip_stream_fetch_traj(h264e_hip_pool_t *pool, int slot, int consumed, int32_t *dst);
 int  h264e_hip_stream_fetch_nals(h264e_hip_pool_t *pool, int slot, uint8_t *dst, uint32_t nbytes);
+/* after the launch has drained: the reconstructed picture of slot `from` becomes the picture of slot `to` (a frame that was
+ * encoded in a spare slot is moved to the slot its frame number owns) */
+int  h264e_hip_stream_copy_picture(h264e_hip_pool_t *pool, int from, int to);
 /* resident input frames back to the host (measurement helper) */
 int  h264e_hip_download_i420(h264e_hip_pool_t *pool, int first, int nframes, uint8_t *host_i420);
 int  h264e_hip_stream_abort(h264e_hip_pool_t *pool);
