@@ -130,6 +130,25 @@ def test_cli_psnr_clip_mode_equals_frame_mode(app, tmp_path):
     assert "YPSNR=40.84 db  UPSNR=45.54 db  VPSNR=46.88 db" in lines[0][0]      # SURVEY.md Appendix B, the reference's own line
 
 
+def test_cli_psnr_with_rate_control_clip_equals_frame_mode(app, tmp_path):
+    """--kbps --psnr: in clip mode the frames behind the first one of a launch run on a speculated QP, some of them as leaves in
+    spare slots whose picture is moved into place afterwards -- stream, per-frame sizes and the PSNR line (computed on the device
+    from those pictures) equal the frame-at-a-time run"""
+    w, h, n = 352, 288, 40
+    c = clips.make("scene", w, h, n)
+    yuv = tmp_path / ("rc_%dx%d.yuv" % (w, h))
+    yuv.write_bytes(c.tobytes())
+    runs = []
+    for extra in (["--clip", "0"], ["--clip", "1"], ["--clip", "1", "--threads", "3"], ["--clip", "0", "--threads", "3"]):
+        out = tmp_path / "o.264"
+        r = _run(["--input", str(yuv), "--output", str(out), "--kbps", "300", "--gop", "30", "--psnr", "x", "--stats", "x"] + extra, str(tmp_path))
+        assert r.returncode == 0, r.stdout.decode()
+        text = r.stdout.decode()
+        runs.append((hashlib.md5(out.read_bytes()).hexdigest(), [l for l in text.splitlines() if l.startswith("frame=")], [l for l in text.splitlines() if "YPSNR" in l]))
+    assert runs[0] == runs[1] and len(runs[0][1]) == n and len(runs[0][2]) == 1
+    assert runs[2] == runs[3] and runs[2][0] != runs[0][0]
+
+
 def test_cli_gpus_option_shards_one_stream(app, tmp_path):
     """--gpus 3 on the one GPU of this box (three clip encoders on device 0): GOP blocks of the 300-frame CIF stream, settled with
     the exact mv_clusters state in stream order; the output equals the reference's single stream"""
