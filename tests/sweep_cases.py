@@ -25,6 +25,8 @@ def cases(n, seed, max_pixels):
             w, h = (w + 3) // 4 * 4, (h + 3) // 4 * 4          # the generator tiles 4x4 blocks
         if name == "pan" and w < 64:
             continue
+        if name == "synth" and (w < 48 or h < 48):
+            continue                                        # synth_v1's foreground box needs room to move
         mode = next(r) % 10
         kw = dict(gop=1 + next(r) % 12, qp=10 + next(r) % 42, speed=[0, 0, 0, 1, 2, 8, 9, 10][next(r) % 8], slices=0, kbps=0)
         nmby = (h + 15) // 16
