@@ -255,6 +255,36 @@ DEV void rv_wait_rect(const RefView &V, int y0, int x1, int y1)
 #endif
 }
 
+/* The same wait inside a lane-group section (wave.h): rectangle and counters differ from group to group, so nothing here goes
+ * through a scalar register; every lane polls until ITS group's rows are there (the loop ends when all lanes have left it). */
+DEV void rv_wait_rect_g(const RefView &V, int y0, int x1, int y1)
+{
+    if (V.far) grp_count(V.far);
+#ifndef H264E_EMU
+    if (!V.dep) return;
+    const int X = imin(imax(x1, 0), V.P.w - 1) >> 4, Ya = imin(imax(y0, 0), V.P.h - 1) >> 4, Yb = imin(imax(y1, 0), V.P.h - 1) >> 4;
+    const int need = imin(X + 2, V.nmbx);
+    for (int Y = Ya; Y <= Yb; Y++)
+    {
+        const bool last = rv_slice_last(V, Y);
+        if (!last && Y != Yb) continue;
+        const GLOBAL_AS int *flag = V.dep + (last ? Y : Y + 1);
+        unsigned spins = 0;
+        for (;;)
+        {
+            const int seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen >= need) break;
+            if (seen < 0) { if (V.fail) *V.fail = seen; break; }
+            if (++spins > V.spin_limit) { if (V.fail) *V.fail = -1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    consumer_acquire();
+#else
+    (void)y0; (void)x1; (void)y1;
+#endif
+}
+
 /* one lane per window row: four 16-byte loads when the window's columns lie inside the picture (uniform test),
  * clamped dword loads at the picture's left/right border */
 DEV void wave_load_window(uint8_t *win, const Plane &P, int wx0, int wy0, int narrow)
@@ -308,6 +338,35 @@ DEV int wave_sad_ref(const RefView &R, int x0, int y0, const uint8_t *b, int w, 
         if (l >= n) return 0;
         int r = l >> (g >> 1), c = l & (g - 1);              /* g is 2 or 4 */
         return (int)sad4_u8(ref_load4(R.P, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
+    });
+}
+
+/* the same for a lane group (wave.h): the block's w*h/4 dwords are dealt to the group's 16 lanes, 16 per pass */
+DEV int grp_sad_ref(const RefView &R, int x0, int y0, const uint8_t *b, int w, int h)
+{
+    const int g = w >> 2, npass = (g*h) >> 4;
+    if (rv_inside(R, x0, y0, x0 + w - 1, y0 + h - 1))
+    {
+        const lu8 *base = rv_ptr(R, x0, y0);
+        return grp_sum([&](int i) -> int {
+            uint32_t s = 0;
+            for (int k = 0; k < npass; k++)
+            {
+                const int d = i + 16*k, r = d >> (g >> 1), c = d & (g - 1);              /* g is 2 or 4 */
+                s = sad4_u8(lds32u(base + r*WIN_STRIDE + 4*c), lds32(b + 16*r + 4*c), s);
+            }
+            return (int)s;
+        });
+    }
+    rv_wait_rect_g(R, y0, x0 + w - 1, y0 + h - 1);
+    return grp_sum([&](int i) -> int {
+        uint32_t s = 0;
+        for (int k = 0; k < npass; k++)
+        {
+            const int d = i + 16*k, r = d >> (g >> 1), c = d & (g - 1);
+            s = sad4_u8(ref_load4(R.P, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), s);
+        }
+        return (int)s;
     });
 }
 
@@ -518,6 +577,23 @@ DEV void wave_interp_luma(const RefView &R, int bx, int by, mv32 mv, int w, int 
         if (l < n)
         {
             int r = l >> (g >> 1), c = l & (g - 1);              /* g is 2 or 4 */
+            lds32_store(dst + 16*r + 4*c, interp_luma4(R, inside, ix + 4*c, iy + r, fx, fy));
+        }
+    }
+    wave_sync();
+}
+
+/* the same for a lane group */
+DEV void grp_interp_luma(const RefView &R, int bx, int by, mv32 mv, int w, int h, uint8_t *dst)
+{
+    const int g = w >> 2, npass = (g*h) >> 4, ix = bx + (mvx(mv) >> 2), iy = by + (mvy(mv) >> 2), fx = mvx(mv) & 3, fy = mvy(mv) & 3;
+    const bool inside = rv_inside_interp(R, ix, iy, w, h);
+    if (!inside) rv_wait_rect_g(R, iy - 2, ix + w + 3, iy + h + 2);
+    GRP_FOR(i)
+    {
+        for (int k = 0; k < npass; k++)
+        {
+            const int d = i + 16*k, r = d >> (g >> 1), c = d & (g - 1);
             lds32_store(dst + 16*r + 4*c, interp_luma4(R, inside, ix + 4*c, iy + r, fx, fy));
         }
     }

@@ -13,6 +13,13 @@
 
 #include "enc_kernels.h"
 
+/* predictor context of the motion search (H:3646-3671 saves and restores it around every partitioning; here every partition type works on
+ * its own copy): the left column, the top-left column and the top row (+ top-right) of 4x4-block vectors */
+struct GCtx { mv32 mv_left[4], mv_tl[4], mv_top[8]; };
+/* sub-pel scratch of the four partition types: 4 planes of w*h bytes each (16x16, 16x8, 8x16, 8x8) */
+#define GSCR_OFF(t) ((t) == 0 ? 0 : (t) == 1 ? 1024 : (t) == 2 ? 1536 : 2048)
+#define GSCR_BYTES 2304
+
 struct RowLds
 {
     /* ---- carried from macroblock to macroblock along the row */
@@ -43,7 +50,9 @@ struct RowLds
     uint32_t df_nz_top;
     int top_type, top_qp;
     alignas(4) uint8_t pix_top[36];                 /* 16 Y, 8 U, 8 V of the macroblock above + 4 Y of the one above-right */
-    mv32 mv[16], mvd[16], cand[20], part_mv[4][4], part_mvd[4][4], ctx_save[12];
+    mv32 mv[16], mvd[16], part_mv[4][4], part_mvd[4][4];
+    GCtx gctx[4];                                   /* the motion search's predictor context, one copy per partition type (lane group) */
+    int gcost[4], gnum[4];                          /* cost and number of partitions of every partition type searched */
     int8_t i4_mode[16];
     alignas(4) uint8_t bs[32];
     I4Scratch i4s;
@@ -58,14 +67,9 @@ struct RowLds
     alignas(16) uint8_t pred[256];
     alignas(16) uint8_t pred_c[128];
     alignas(16) uint8_t skip_pred[256];
-    alignas(16) uint8_t test[256];
-    alignas(16) uint8_t blk[256];
-    alignas(16) uint8_t p00[256];
-    alignas(16) uint8_t p02[256];
-    alignas(16) uint8_t p20[256];
-    alignas(16) uint8_t p22[256];
+    alignas(16) uint8_t gtest[4][256];              /* prediction of every partition type searched (gtest[0] doubles as scratch of the 16x16 intra test) */
+    alignas(16) uint8_t gscr[GSCR_BYTES];           /* sub-pel search: the full-sample block and the three half-sample planes of the partition a group works on */
     alignas(16) uint8_t tt[256];
-    alignas(16) uint8_t skip_tmp[4][256];           /* quarter-pel candidates of the sub-pel search */
     alignas(16) uint8_t i4rec[17*24];               /* intra 4x4 working picture: row 0 / column 0 = neighbours */
     alignas(16) uint8_t ytile[20*YT_STRIDE];
     alignas(16) uint8_t ctile[2][10*CT_STRIDE];
@@ -108,20 +112,20 @@ DEV rect_t mv_qlimit(const MbCtx &m) { rect_t r = { m.G->lim_x0 + 16, m.G->lim_y
 DEV int med3(int a, int b, int c) { return imax(imin(imax(a, b), c), imin(a, b)); }
 
 /* H:3696-3715 me_mv_medianpredictor_put, 4x4-block units */
-DEV void mvp_put(RowLds &L, int x, int y, int w, int h, mv32 mv)
+DEV void mvp_put_arr(mv32 *mv_left, mv32 *mv_tl, mv32 *mv_top, int x, int y, int w, int h, mv32 mv)
 {
-    L.mv_tl[y] = L.mv_top[x + w - 1];
-    for (int i = 1; i < h; i++) L.mv_tl[y + i] = mv;
-    for (int i = 0; i < h; i++) L.mv_left[y + i] = mv;
-    for (int i = 0; i < w; i++) L.mv_top[x + i] = mv;
+    mv_tl[y] = mv_top[x + w - 1];
+    for (int i = 1; i < h; i++) mv_tl[y + i] = mv;
+    for (int i = 0; i < h; i++) mv_left[y + i] = mv;
+    for (int i = 0; i < w; i++) mv_top[x + i] = mv;
 }
+DEV void mvp_put(RowLds &L, int x, int y, int w, int h, mv32 mv) { mvp_put_arr(L.mv_left, L.mv_tl, L.mv_top, x, y, w, h, mv); }
 
 /* H:3720-3872 me_mv_medianpredictor_get */
-DEV mv32 mvp_get(const RowLds &L, const MbCtx &m, int x, int y, int w, int h)
+DEV mv32 mvp_get_arr(const mv32 *mv_left, const mv32 *mv_tl, const mv32 *mv_top, int flag, int x, int y, int w, int h)
 {
-    const int flag = m.avail;
     int type = 1;
-    mv32 a = L.mv_left[y], b = L.mv_top[x], c = L.mv_top[x + w], d = L.mv_tl[y], ret = 0;
+    mv32 a = mv_left[y], b = mv_top[x], c = mv_top[x + w], d = mv_tl[y], ret = 0;
     if (!x)
     {
         if (!(flag & AV_L)) a = MV_NA;
@@ -162,8 +166,9 @@ DEV mv32 mvp_get(const RowLds &L, const MbCtx &m, int x, int y, int w, int h)
         ret = mvmk(med3(mvx(a), mvx(b), mvx(c)), med3(mvy(a), mvy(b), mvy(c)));
     }
 #undef OK
-    return (mv32)uni(ret);
+    return ret;
 }
+DEV mv32 mvp_get(const RowLds &L, const MbCtx &m, int x, int y, int w, int h) { return (mv32)uni(mvp_get_arr(L.mv_left, L.mv_tl, L.mv_top, m.avail, x, y, w, h)); }
 
 /* ------------------------------------------------------------------ motion search */
 
@@ -183,11 +188,13 @@ DEV void set_range(mv32 &pnt, rect_t &range, const rect_t &limit, int mby_q)
  * the macroblock (quarter-pel), so the block sits at (px,py) + (mv >> 2) in the reference picture.
  * The uint16 SAD cache with its 0xffff sentinel is observable behaviour.
  * dst (LDS, stride 16) receives the prediction of the returned vector.
+ * Runs inside a LANE-GROUP section (wave.h): the four partition types of a macroblock are searched side by side, one 16-lane group
+ * each, so every "scalar" of this function is a per-lane value that agrees inside the group; the block's dwords are dealt to the
+ * group's lanes 16 per pass.  scr = the group's sub-pel scratch (4 planes of w*h bytes).
  */
-DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_t &range_, mv32 mv_pred, int min_sad, int w, int h, uint8_t *dst)
+DEV int diamond_g(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_t &range, mv32 mv_pred, int min_sad, int w, int h, uint8_t *dst, uint8_t *scr)
 {
     const RefView &R = m.rv;
-    const rect_t range = { uni(range_.x0), uni(range_.y0), uni(range_.x1), uni(range_.y1) };    /* scalar registers: the scan below is scalar control code */
     const uint8_t *b = L.inp + 16*py + px;
     /* the reference's uint16 cache[8]: four 16-bit fields each in `cur` (neighbours of the centre) and `prv` */
     uint64_t cur, prv;
@@ -197,18 +204,15 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
 #define DY(d) ((d) == 2 ? 4 : (d) == 3 ? -4 : 0)
     int dir, cloop, dir_prev, cost;
     mv32 v;
-    mv = (mv32)uni(mv); mv_pred = (mv32)uni(mv_pred); min_sad = uni(min_sad);
-    px = uni(px); py = uni(py); w = uni(w); h = uni(h);
-    const int g = w >> 2, n = g*h;
+    const int g = w >> 2, npass = (g*h) >> 4;
     PCOUNT(L, 18);
-    PTIC();
     for (;;)
     {
         dir = 0; cloop = 4; dir_prev = -1;
         cur = prv = ~0ull;
-        /* SADs of the centre's four neighbours are taken in one batch (one lane-parallel pass, two packed reductions) the
+        /* SADs of the centre's four neighbours are taken in one batch (one pass of the group's lanes, two packed reductions) the
          * first time the reference's sequential scan asks for one of them; the scan itself is unchanged */
-        int have = 0, bs0 = 0, bs1 = 0, bs2 = 0, bs3 = 0;
+        int have = 0, bs[4] = { 0, 0, 0, 0 };
         do
         {
             v = mvadd(mv, mvmk(DX(dir), DY(dir)));
@@ -218,7 +222,6 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
                 if (!(have & (1 << dir)))
                 {
                     PCOUNT(L, 17);
-                    PTIC();
                     int want = 0, s4[4];
 #pragma unroll
                     for (int d = 0; d < 4; d++)
@@ -230,46 +233,44 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
                     if (rv_inside(R, cx - 1, cy - 1, cx + w, cy + h))
                     {
                         const lu8 *base = rv_ptr(R, cx, cy);
-                        wave_sum4([&](int l, int *sv) {
-                            if (l >= n) return;
-                            const int r = l >> (g >> 1), c4 = l & (g - 1);
-                            const uint32_t in4 = lds32(b + 16*r + 4*c4);
-                            const lu8 *p = base + r*WIN_STRIDE + 4*c4;
-                            /* all four neighbours lie inside the window: issue the loads together (one LDS wait instead of four);
-                             * sums of directions that are not wanted are simply not looked at */
-                            const uint32_t a0 = lds32u(p + 1), a1 = lds32u(p - 1), a2 = lds32u(p + WIN_STRIDE), a3 = lds32u(p - WIN_STRIDE);
-                            sv[0] = (int)sad4_u8(a0, in4, 0); sv[1] = (int)sad4_u8(a1, in4, 0);
-                            sv[2] = (int)sad4_u8(a2, in4, 0); sv[3] = (int)sad4_u8(a3, in4, 0);
+                        grp_sum4([&](int i, int *sv) {
+                            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+                            for (int k = 0; k < npass; k++)
+                            {
+                                const int d = i + 16*k, r = d >> (g >> 1), c4 = d & (g - 1);
+                                const uint32_t in4 = lds32(b + 16*r + 4*c4);
+                                const lu8 *p = base + r*WIN_STRIDE + 4*c4;
+                                /* all four neighbours lie inside the window: issue the loads together (one LDS wait instead of four);
+                                 * sums of directions that are not wanted are simply not looked at */
+                                const uint32_t a0 = lds32u(p + 1), a1 = lds32u(p - 1), a2 = lds32u(p + WIN_STRIDE), a3 = lds32u(p - WIN_STRIDE);
+                                t0 = sad4_u8(a0, in4, t0); t1 = sad4_u8(a1, in4, t1); t2 = sad4_u8(a2, in4, t2); t3 = sad4_u8(a3, in4, t3);
+                            }
+                            sv[0] = (int)t0; sv[1] = (int)t1; sv[2] = (int)t2; sv[3] = (int)t3;
                         }, s4);
                     } else
                     {
-                        rv_wait_rect(R, cy - 1, cx + w, cy + h);
-                        wave_sum4([&](int l, int *sv) {
-                            if (l >= n) return;
-                            const int r = l >> (g >> 1), c4 = l & (g - 1);
-                            const uint32_t in4 = lds32(b + 16*r + 4*c4);
-                            if (want & 1) sv[0] = (int)sad4_u8(ref_load4(R.P, cx + 4*c4 + 1, cy + r), in4, 0);
-                            if (want & 2) sv[1] = (int)sad4_u8(ref_load4(R.P, cx + 4*c4 - 1, cy + r), in4, 0);
-                            if (want & 4) sv[2] = (int)sad4_u8(ref_load4(R.P, cx + 4*c4, cy + r + 1), in4, 0);
-                            if (want & 8) sv[3] = (int)sad4_u8(ref_load4(R.P, cx + 4*c4, cy + r - 1), in4, 0);
+                        rv_wait_rect_g(R, cy - 1, cx + w, cy + h);
+                        grp_sum4([&](int i, int *sv) {
+                            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+                            for (int k = 0; k < npass; k++)
+                            {
+                                const int d = i + 16*k, r = d >> (g >> 1), c4 = d & (g - 1);
+                                const uint32_t in4 = lds32(b + 16*r + 4*c4);
+                                if (want & 1) t0 = sad4_u8(ref_load4(R.P, cx + 4*c4 + 1, cy + r), in4, t0);
+                                if (want & 2) t1 = sad4_u8(ref_load4(R.P, cx + 4*c4 - 1, cy + r), in4, t1);
+                                if (want & 4) t2 = sad4_u8(ref_load4(R.P, cx + 4*c4, cy + r + 1), in4, t2);
+                                if (want & 8) t3 = sad4_u8(ref_load4(R.P, cx + 4*c4, cy + r - 1), in4, t3);
+                            }
+                            sv[0] = (int)t0; sv[1] = (int)t1; sv[2] = (int)t2; sv[3] = (int)t3;
                         }, s4);
                     }
-                    /* SAD + vector cost of the four neighbours; the four costs are computed in four lanes at once */
-#ifdef H264E_EMU
-                    bs0 = s4[0] + mv_cost(m, mvadd(mv, mvmk(DX(0), DY(0))), mv_pred); bs1 = s4[1] + mv_cost(m, mvadd(mv, mvmk(DX(1), DY(1))), mv_pred);
-                    bs2 = s4[2] + mv_cost(m, mvadd(mv, mvmk(DX(2), DY(2))), mv_pred); bs3 = s4[3] + mv_cost(m, mvadd(mv, mvmk(DX(3), DY(3))), mv_pred);
-#else
-                    {
-                        const int dl = (int)threadIdx.x & 3;
-                        const int cl = mv_cost(m, mvadd(mv, mvmk(DX(dl), DY(dl))), mv_pred);
-                        bs0 = s4[0] + __builtin_amdgcn_readlane(cl, 0); bs1 = s4[1] + __builtin_amdgcn_readlane(cl, 1);
-                        bs2 = s4[2] + __builtin_amdgcn_readlane(cl, 2); bs3 = s4[3] + __builtin_amdgcn_readlane(cl, 3);
-                    }
-#endif
+                    /* SAD + vector cost of the four neighbours */
+                    int c4v[4];
+                    grp_eval4([&](int d) -> int { return mv_cost(m, mvadd(mv, mvmk(DX(d), DY(d))), mv_pred); }, c4v);
+                    bs[0] = s4[0] + c4v[0]; bs[1] = s4[1] + c4v[1]; bs[2] = s4[2] + c4v[2]; bs[3] = s4[3] + c4v[3];
                     have = want;
-                    PTOC(L, 16);
                 }
-                cost = dir == 0 ? bs0 : dir == 1 ? bs1 : dir == 2 ? bs2 : bs3;
+                cost = dir == 0 ? bs[0] : dir == 1 ? bs[1] : dir == 2 ? bs[2] : bs[3];
                 CSET(cur, dir, (uint32_t)cost);
                 if (cost < min_sad)
                 {
@@ -293,9 +294,7 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
         v = mvadd(mv, mvmk(DX(pri) + DX(sec), DY(pri) + DY(sec)));
         if (in_rect(v, range))
         {
-            PTIC();
-            cost = wave_sad_ref(R, px + (mvx(v) >> 2), py + (mvy(v) >> 2), b, w, h) + mv_cost(m, v, mv_pred);
-            PTOC(L, 23);
+            cost = grp_sad_ref(R, px + (mvx(v) >> 2), py + (mvy(v) >> 2), b, w, h) + mv_cost(m, v, mv_pred);
             if (cost < min_sad)
             {
                 mv = v;
@@ -311,85 +310,133 @@ DEV int diamond(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_
 #undef DX
 #undef DY
 
-    PTOC(L, 15);
-    STAMP(L, 5);
     if (!(m.speed < 9 && in_rect(mv, mv_qlimit(m))))
     {
-        wave_interp_luma(R, px, py, mv, w, h, dst);
-        STAMP(L, 6);
+        grp_interp_luma(R, px, py, mv, w, h, dst);
         return min_sad;
     }
     {
         /* H:5083-5174: seven sub-pel probes around the full-pel winner -- half-pels towards the cheaper vertical and the
          * cheaper horizontal neighbour (02, 20), their diagonal (22), and the quarter-pels between them (01, 10, 11, 12).
          * The reference always evaluates all seven, in this order, keeping the first strict minimum; here every lane builds
-         * its 4 samples of all seven (plus the full-pel block) in one pass and the seven SADs are reduced together. */
+         * its 4 samples of all seven (plus the full-pel block) in one pass and the seven SADs are reduced together.  The
+         * full-sample block and the three half-sample planes go to the group's scratch; the quarter-sample candidates are
+         * their rounded averages and are formed again only for the winner. */
         mv32 pq = mvmk(0, -1), sq = mvmk(-1, 0);
         uint32_t ms1 = c1, ms2 = c3;
         if (c3 >= c2) { pq = mvmk(0, 1); ms2 = c2; }
         if (c1 >= c0) { sq = mvmk(1, 0); ms1 = c0; }
-        if (ms2 > ms1) { mv32 s = sq; sq = pq; pq = s; }
+        if (ms2 > ms1) { mv32 sw = sq; sq = pq; pq = sw; }
         const mv32 vdg = mvadd(pq, sq);
         const mv32 v02 = mvadd(mv, mvadd(pq, pq)), v01 = mvadd(mv, pq), v20 = mvadd(mv, mvadd(sq, sq)), v10 = mvadd(mv, sq);
         const mv32 v11 = mvadd(mv, vdg), v22 = mvadd(mv, mvadd(vdg, vdg)), v12 = mvadd(mv, mvadd(pq, vdg));
         int s8[8];
-        const int fx0 = px + (mvx(mv) >> 2), fy0 = py + (mvy(mv) >> 2);
+        const int fx0 = px + (mvx(mv) >> 2), fy0 = py + (mvy(mv) >> 2), plane = w*h;
         const bool inside = rv_inside(R, fx0 - 5, fy0 - 3, fx0 + w + 4, fy0 + h + 3);      /* every probe is within one sample of mv */
-        if (!inside) rv_wait_rect(R, fy0 - 3, fx0 + w + 4, fy0 + h + 3);
+        if (!inside) rv_wait_rect_g(R, fy0 - 3, fx0 + w + 4, fy0 + h + 3);
         /* the 2x2 integer cell that holds the three half-sample positions: vdg = (+-1, +-1) says on which side of (x,y) it lies */
         const int hp_ox = mvx(vdg) < 0 ? 1 : 0, hp_oy = mvy(vdg) < 0 ? 1 : 0, hp_pq_vertical = mvx(pq) == 0;
-        wave_sum8([&](int l, int *sv) {
-            if (l >= n) return;
-            const int r = l >> (g >> 1), c4 = l & (g - 1), o = 16*r + 4*c4;
-            const uint32_t in4 = lds32(b + o);
-#define IP(vv) interp_luma4(R, inside, px + (mvx(vv) >> 2) + 4*c4, py + (mvy(vv) >> 2) + r, mvx(vv) & 3, mvy(vv) & 3)
 #define AVG4(x, y) (((x) | (y)) - ((((x) ^ (y)) >> 1) & 0x7f7f7f7fu))                    /* per-byte (x + y + 1) >> 1 */
-            uint32_t q00, q02, q20, q22;
-            if (inside)
+        grp_sum8([&](int i, int *sv) {
+            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+            for (int k = 0; k < npass; k++)
             {
-                /* all three half-sample planes from one pass over the window (halfpel3_win) */
-                const int ox = hp_ox, oy = hp_oy;
-                const hp4_t hp = halfpel3_win(rv_ptr(R, fx0 + 4*c4 - ox, fy0 + r - oy), ox, oy);
-                q00 = hp.x; q22 = hp.w;
-                q02 = hp_pq_vertical ? hp.z : hp.y;
-                q20 = hp_pq_vertical ? hp.y : hp.z;
-            } else
-            {
-                q00 = IP(mv); q02 = IP(v02); q20 = IP(v20); q22 = IP(v22);
-            }
+                const int d = i + 16*k, r = d >> (g >> 1), c4 = d & (g - 1), o = w*r + 4*c4;
+                const uint32_t in4 = lds32(b + 16*r + 4*c4);
+#define IP(vv) interp_luma4(R, false, px + (mvx(vv) >> 2) + 4*c4, py + (mvy(vv) >> 2) + r, mvx(vv) & 3, mvy(vv) & 3)
+                uint32_t q00, q02, q20, q22;
+                if (inside)
+                {
+                    /* all three half-sample planes from one pass over the window (halfpel3_win) */
+                    const hp4_t hp = halfpel3_win(rv_ptr(R, fx0 + 4*c4 - hp_ox, fy0 + r - hp_oy), hp_ox, hp_oy);
+                    q00 = hp.x; q22 = hp.w;
+                    q02 = hp_pq_vertical ? hp.z : hp.y;
+                    q20 = hp_pq_vertical ? hp.y : hp.z;
+                } else
+                {
+                    q00 = IP(mv); q02 = IP(v02); q20 = IP(v20); q22 = IP(v22);
+                }
 #undef IP
-            const uint32_t q01 = AVG4(q00, q02), q10 = AVG4(q00, q20), q11 = AVG4(q02, q20), q12 = AVG4(q22, q02);
-#undef AVG4
-            lds32_store(L.p00 + o, q00);
-            lds32_store(L.p02 + o, q02); lds32_store(L.p20 + o, q20); lds32_store(L.p22 + o, q22);
-            lds32_store(L.skip_tmp[0] + o, q01); lds32_store(L.skip_tmp[1] + o, q10);
-            lds32_store(L.skip_tmp[2] + o, q11); lds32_store(L.skip_tmp[3] + o, q12);
-            sv[0] = (int)sad4_u8(q02, in4, 0); sv[1] = (int)sad4_u8(q01, in4, 0); sv[2] = (int)sad4_u8(q20, in4, 0);
-            sv[3] = (int)sad4_u8(q10, in4, 0); sv[4] = (int)sad4_u8(q11, in4, 0); sv[5] = (int)sad4_u8(q22, in4, 0);
-            sv[6] = (int)sad4_u8(q12, in4, 0);
+                const uint32_t q01 = AVG4(q00, q02), q10 = AVG4(q00, q20), q11 = AVG4(q02, q20), q12 = AVG4(q22, q02);
+                lds32_store(scr + o, q00); lds32_store(scr + plane + o, q02); lds32_store(scr + 2*plane + o, q20); lds32_store(scr + 3*plane + o, q22);
+                t0 = sad4_u8(q02, in4, t0); t1 = sad4_u8(q01, in4, t1); t2 = sad4_u8(q20, in4, t2);
+                t3 = sad4_u8(q10, in4, t3); t4 = sad4_u8(q11, in4, t4); t5 = sad4_u8(q22, in4, t5);
+                t6 = sad4_u8(q12, in4, t6);
+            }
+            sv[0] = (int)t0; sv[1] = (int)t1; sv[2] = (int)t2; sv[3] = (int)t3; sv[4] = (int)t4; sv[5] = (int)t5; sv[6] = (int)t6;
         }, s8);
         wave_sync();
-        int best = -1;
-        mv32 vbest = (mv32)uni(mv);
-#ifdef H264E_EMU
-#define TRY(i, vv) { const mv32 vu = (vv); const int cst = s8[i] + mv_cost(m, vu, mv_pred); if (cst < min_sad) { min_sad = cst; vbest = vu; best = i; } }
-#else
-        /* the seven vector costs in seven lanes (one pass of VALU code instead of seven scalar ones), read back with v_readlane */
-        const int ln = (int)threadIdx.x;
-        const mv32 vln = ln == 0 ? v02 : ln == 1 ? v01 : ln == 2 ? v20 : ln == 3 ? v10 : ln == 4 ? v11 : ln == 5 ? v22 : v12;
-        const int cln = mv_cost(m, vln, mv_pred);
-        /* uni(): keeps the scalar bookkeeping below from being merged with the same expressions inside the lane code above */
-#define TRY(i, vv) { const mv32 vu = (mv32)uni(vv); const int cst = s8[i] + __builtin_amdgcn_readlane(cln, i); if (cst < min_sad) { min_sad = cst; vbest = vu; best = i; } }
-#endif
+        int best = -1, c8[8];
+        mv32 vbest = mv;
+        /* the seven vector costs */
+        grp_eval8([&](int j) -> int {
+            const mv32 vj = j == 0 ? v02 : j == 1 ? v01 : j == 2 ? v20 : j == 3 ? v10 : j == 4 ? v11 : j == 5 ? v22 : v12;
+            return mv_cost(m, vj, mv_pred);
+        }, c8);
+#define TRY(j, vv) { const int cst = s8[j] + c8[j]; if (cst < min_sad) { min_sad = cst; vbest = (vv); best = j; } }
         TRY(0, v02) TRY(1, v01) TRY(2, v20) TRY(3, v10) TRY(4, v11) TRY(5, v22) TRY(6, v12)
 #undef TRY
-        const uint8_t *src = best < 0 ? L.p00 : best == 0 ? L.p02 : best == 1 ? L.skip_tmp[0] : best == 2 ? L.p20 : best == 3 ? L.skip_tmp[1] :
-                             best == 4 ? L.skip_tmp[2] : best == 5 ? L.p22 : L.skip_tmp[3];
-        wave_copy_wh(dst, src, w, h);
+        /* the winner's samples: a stored plane, or the rounded average of two of them */
+        const int pa = best < 0 ? 0 : best == 0 ? 1 : best == 1 ? 0 : best == 2 ? 2 : best == 3 ? 0 : best == 4 ? 1 : best == 5 ? 3 : 3;
+        const int pb = best == 1 ? 1 : best == 3 ? 2 : best == 4 ? 2 : best == 6 ? 1 : pa;
+        GRP_FOR(i)
+        {
+            for (int k = 0; k < npass; k++)
+            {
+                const int d = i + 16*k, r = d >> (g >> 1), c4 = d & (g - 1), o = w*r + 4*c4;
+                const uint32_t x = lds32(scr + pa*plane + o), y = lds32(scr + pb*plane + o);
+                lds32_store(dst + 16*r + 4*c4, AVG4(x, y));          /* the average of a plane with itself is the plane */
+            }
+        }
+#undef AVG4
+        wave_sync();
         mv = vbest;
     }
-    STAMP(L, 6);
     return min_sad;
+}
+
+/*
+ * One partition type of H:5283-5524's partition loop, run by one lane group: t = 0 16x16, 1 16x8, 2 8x16, 3 8x8.  The partitions of a
+ * type are a serial chain through their vector predictors (the group's own copy of the predictor context, L.gctx[t]); the four types
+ * are independent of each other: every one starts from the macroblock's predictor context (H:3646-3671).  Leaves the type's cost in
+ * L.gcost[t], its vectors in L.part_mv[t] / L.part_mvd[t] and its prediction in L.gtest[t].
+ */
+DEV void search_type(RowLds &L, const MbCtx &m, int t, mv32 mv_best, int sad_best0, const rect_t &lim)
+{
+    GCtx &X = L.gctx[t];
+    int imv = 0, part_sad = MUL_LAMBDA(t == 0 ? 1 : t == 3 ? 12 : 4, m.lambda_q4);
+    const int w = (t & 2) ? 8 : 16, h = (t & 1) ? 8 : 16;
+    int px = 0, py = 0;
+    uint8_t *test = L.gtest[t], *scr = L.gscr + GSCR_OFF(t);
+    for (;;)
+    {
+        rect_t range;
+        mv32 mvabs = mb_abs(m, mv_best);
+        int sad_best = sad_best0;
+        const mv32 mvp = mvp_get_arr(X.mv_left, X.mv_tl, X.mv_top, m.avail, px >> 2, py >> 2, w >> 2, h >> 2);
+        if (!t) set_range(mvabs, range, lim, m.y*64 + py*4);
+        else
+        {
+            mvabs = mvround(mb_abs(m, mvp));
+            set_range(mvabs, range, lim, m.y*64 + py*4);
+            sad_best = grp_sad_ref(m.rv, px + (mvx(mvabs) >> 2), py + (mvy(mvabs) >> 2), L.inp + 16*py + px, w, h)
+                     + mv_cost(m, mvabs, mb_abs(m, mvp));
+        }
+        part_sad += diamond_g(L, m, px, py, mvabs, range, mb_abs(m, mvp), sad_best, w, h, test + 16*py + px, scr);
+        const mv32 mv = mvsub(mvabs, mvmk(m.x*64, m.y*64));
+        L.part_mvd[t][imv] = mvsub(mv, mvp);
+        L.part_mv[t][imv++] = mv;
+        mvp_put_arr(X.mv_left, X.mv_tl, X.mv_top, px >> 2, py >> 2, w >> 2, h >> 2, mv);
+        wave_sync();
+        px = (px + w) & 15;
+        if (!px)
+        {
+            py = (py + h) & 15;
+            if (!py) break;
+        }
+    }
+    L.gcost[t] = part_sad;
+    L.gnum[t] = imv;
 }
 
 /* H:5224-5257 mb_inter_partition */
@@ -550,57 +597,32 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
     sad_best += mv_cost(m, mv_best, mv_pred16);
     STAMP(L, 4);
 
-    /* H:3646-3671: every partitioning is tried from the same predictor state */
-    for (int i = 0; i < 4; i++) { L.ctx_save[i] = L.mv_left[i]; L.ctx_save[4 + i] = L.mv_tl[i]; L.ctx_save[8 + i] = L.mv_top[i]; }
+    /* H:3646-3671: every partitioning is tried from the same predictor state; H:5283-5524's loop over the partition types runs as
+     * four lane groups side by side (search_type).  The reference takes a type when its cost is strictly below the best so far, in the
+     * order 16x16, 16x8, 8x16, 8x8 (H:5500): the minimum, the earliest type on ties. */
+    const int types = 1 | (prefer[1] ? 2 : 0) | (prefer[2] ? 4 : 0) | (prefer[3] ? 8 : 0);
+    WAVE_FOR(l)
+    {
+        const int i = l & 15;
+        mv32 *c = &L.gctx[l >> 4].mv_left[0];              /* the 16 words of a GCtx: left[4], tl[4], top[8] */
+        c[i] = i < 4 ? L.mv_left[i] : i < 8 ? L.mv_tl[i - 4] : i < 13 ? L.mv_top[i - 8] : 0;
+    }
+    wave_sync();
+    GRP_EACH(t)
+    {
+        if ((types >> t) & 1) search_type(L, m, t, mv_best, sad_best, lim);
+    }
+    wave_sync();
+    STAMP(L, 5);
     m.cost = 0xffffff;
     int best_n = 0;
     for (int t = 0; t < 4; t++)
-    {
-        int imv = 0, part_sad = MUL_LAMBDA(t == 0 ? 1 : t == 3 ? 12 : 4, m.lambda_q4);
-        const int w = (t & 2) ? 8 : 16, h = (t & 1) ? 8 : 16;
-        int px = 0, py = 0, lost = 0;
-        if (!(t == 0 ? prefer[0] : t == 1 ? prefer[1] : t == 2 ? prefer[2] : prefer[3])) continue;
-        for (;;)
+        if ((types >> t) & 1)
         {
-            PTIC();
-            rect_t range;
-            mv32 mvabs = mb_abs(m, mv_best);
-            const mv32 mvp = mvp_get(L, m, px >> 2, py >> 2, w >> 2, h >> 2);
-            if (!t) set_range(mvabs, range, lim, m.y*64 + py*4);
-            else
-            {
-                mvabs = mvround(mb_abs(m, mvp));
-                set_range(mvabs, range, lim, m.y*64 + py*4);
-                sad_best = wave_sad_ref(R, px + (mvx(mvabs) >> 2), py + (mvy(mvabs) >> 2), L.inp + 16*py + px, w, h)
-                         + mv_cost(m, mvabs, mb_abs(m, mvp));
-            }
-            PTOC(L, 27);
-            part_sad += diamond(L, m, px, py, mvabs, range, mb_abs(m, mvp), sad_best, w, h, L.test + 16*py + px);
-            /* the partition costs only add up: once they reach the best cost so far this partitioning cannot win (H:5500 is a
-             * strict "<"), and nothing else of it is observable -- the predictor context is restored below */
-            if (part_sad >= m.cost) { lost = 1; break; }
-            const mv32 mv = mvsub(mvabs, mvmk(m.x*64, m.y*64));
-            L.part_mvd[t][imv] = mvsub(mv, mvp);
-            L.part_mv[t][imv++] = mv;
-            mvp_put(L, px >> 2, py >> 2, w >> 2, h >> 2, mv);
-            wave_sync();
-            px = (px + w) & 15;
-            if (!px)
-            {
-                py = (py + h) & 15;
-                if (!py) break;
-            }
+            const int c = uni(L.gcost[t]);
+            if (c < m.cost) { m.cost = c; m.type = t; best_n = uni(L.gnum[t]); }
         }
-        for (int i = 0; i < 4; i++) { L.mv_left[i] = L.ctx_save[i]; L.mv_tl[i] = L.ctx_save[4 + i]; L.mv_top[i] = L.ctx_save[8 + i]; }
-        wave_sync();
-        if (!lost && part_sad < m.cost)
-        {
-            wave_copy_wh(L.pred, L.test, 16, 16);
-            m.cost = part_sad;
-            m.type = t;
-            best_n = imv;
-        }
-    }
+    wave_copy_wh(L.pred, L.gtest[m.type], 16, 16);
     for (int i = 0; i < best_n; i++) { L.mv[i] = L.part_mv[m.type][i]; L.mvd[i] = L.part_mvd[m.type][i]; }
     wave_sync();
 
@@ -628,13 +650,13 @@ DEV void intra16_choose(RowLds &L, MbCtx &m)
     else if (dy > 30 + 3*dx && dx < (100 + 50 - m.qp) && (v & 2)) mode = 1;
     else mode = 2;
     m.i16_mode = mode;
-    wave_pred16(L.test, L.pix_left, L.pix_top, m.avail, mode);
-    int sad = wave_sad_lds_q(L.inp, L.test, sad4) + MUL_LAMBDA(ue_len((uint32_t)mode + 1), m.lambda_q4) + m.lambda_i16;
+    wave_pred16(L.gtest[0], L.pix_left, L.pix_top, m.avail, mode);
+    int sad = wave_sad_lds_q(L.inp, L.gtest[0], sad4) + MUL_LAMBDA(ue_len((uint32_t)mode + 1), m.lambda_q4) + m.lambda_i16;
     if (sad < m.cost)
     {
         m.cost = sad;
         m.type = 6;
-        wave_copy_wh(L.pred, L.test, 16, 16);
+        wave_copy_wh(L.pred, L.gtest[0], 16, 16);
     }
 }
 

@@ -12,7 +12,7 @@
  * stdout carries "sizeof_persist = %d sizeof_scratch = %d" and, with --stats, "frame=%d, bytes=%d" (T:568, T:650).
  * --threads N (T:34-111, T:163) = N row-band slices per frame, the bitstream of the reference built with -DH264E_MAX_THREADS
  * (no host threads are involved here: the slices are wavefronts of the same kernel launch).
- * Not kept: --gen (libm-dependent synthetic input), --denoise.
+ * Not kept: --gen (libm-dependent synthetic input), --denoise: both are REFUSED (error line, exit 1, no output file).
  *
  * Extras (new option names, also argv-consuming): --device N; --clip 1 (THE DEFAULT) streams the file through the clip encoder
  * (H264E_clip_*: consecutive frames as a temporal wavefront on the GPU, same bitstream, bounded host memory whatever the file size;
@@ -31,6 +31,7 @@ static struct
     char input_file[1024], output_file[1024], recon_file[1024];
     int have_input, have_output;
     int gop, qp, kbps, max_frames, speed, stats, psnr, device, clip, chains, threads, gpus;
+    int unsupported;                    /* a reference option this encoder refuses was given: no stream is written, exit 1 */
 } cmd;
 
 static int starts(const char *pattern, const char *p) { return !strncmp(pattern, p, strlen(pattern)); }
@@ -38,7 +39,15 @@ static int starts(const char *pattern, const char *p) { return !strncmp(pattern,
 static void parse_long(const char *p, const char *val)
 {
     const char *v = val ? val : "";
-    if (starts("gop", p)) cmd.gop = atoi(v);
+    /* T:135 --gen and T:163 --denoise are options of the reference this encoder does not implement: a stream that silently differs
+     * from the reference's would be worse than none, so they end the run (main: exit 1) instead of being skipped like a typo */
+    if (starts("gen", p) || starts("denoise", p))
+    {
+        printf("ERROR: option --%s is not supported by the MI355X encoder (reference-only: %s)\n", p,
+               starts("gen", p) ? "libm-generated synthetic input" : "temporal denoiser");
+        cmd.unsupported = 1;
+    }
+    else if (starts("gop", p)) cmd.gop = atoi(v);
     else if (starts("qp", p)) cmd.qp = atoi(v);
     else if (starts("kbps", p)) cmd.kbps = atoi(v);
     else if (starts("maxframes", p)) cmd.max_frames = atoi(v);
@@ -80,6 +89,7 @@ static int read_cmdline(int argc, char **argv)
             return 0;
         }
     }
+    if (cmd.unsupported) return 0;
     if (!cmd.have_input)
     {
         printf("Usage:\n    encode_app [options] --input <input[frame_size].yuv> --output <output.264>\n"
@@ -206,14 +216,18 @@ static void *feeder_thread(void *arg)
     return NULL;
 }
 
-typedef struct { feeder_t *f; H264E_clip_t *clip; int resident, inflight /* buffer being copied, or -1 */, next_buf; } pump_t;
+typedef struct { feeder_t *f; H264E_clip_t *clip; int resident, inflight /* buffer being copied, or -1 */, next_buf; int failed /* an upload was refused or lost: H264E_last_error() says why */; } pump_t;
 
 /* idle hook: finish the copy in flight, start the next one if a buffer is ready and the input ring has room */
 static void pump(void *token)
 {
     pump_t *p = (pump_t *)token;
     feeder_t *f = p->f;
-    if (p->inflight >= 0 && H264E_clip_upload_poll(p->clip) == 1)
+    int st;
+    if (p->failed) return;
+    st = p->inflight >= 0 ? H264E_clip_upload_poll(p->clip) : 0;
+    if (st < 0) { p->failed = 1; return; }              /* the copy stream reported an error (lost device, ...) */
+    if (st == 1)
     {
         pthread_mutex_lock(&f->mu);
         f->have[p->inflight] = 0;
@@ -228,8 +242,9 @@ static void pump(void *token)
         n = f->have[p->next_buf]; first = f->first[p->next_buf];
         pthread_mutex_unlock(&f->mu);
         H264E_clip_position(p->clip, &next_frame, NULL);
-        if (n && first + n - p->resident <= next_frame && !H264E_clip_upload_async(p->clip, first, n, f->buf[p->next_buf]))
+        if (n && first + n - p->resident <= next_frame)
         {
+            if (H264E_clip_upload_async(p->clip, first, n, f->buf[p->next_buf])) { p->failed = 1; return; }
             p->inflight = p->next_buf;
             p->next_buf ^= 1;
         }
@@ -304,7 +319,7 @@ static int shard_encode_from(shard_t *s, int from)
     fd.fin = fin; fd.fsz = fsz; fd.nframes = s->nframes - from; fd.base = from; fd.chunk = s->chunk;
     fd.buf[0] = s->stage[0]; fd.buf[1] = s->stage[1];
     pthread_mutex_init(&fd.mu, NULL); pthread_cond_init(&fd.cv, NULL);
-    pp.f = &fd; pp.clip = s->clip; pp.resident = s->par.resident_frames; pp.inflight = -1; pp.next_buf = 0;
+    pp.f = &fd; pp.clip = s->clip; pp.resident = s->par.resident_frames; pp.inflight = -1; pp.next_buf = 0; pp.failed = 0;
     H264E_clip_set_idle_hook(s->clip, pump, &pp);
     s->mem_len = s->foff[from];
     if (pthread_create(&th, NULL, feeder_thread, &fd)) { printf("ERROR: cannot start the reader thread\n"); fclose(fin); return 1; }
@@ -314,9 +329,17 @@ static int shard_encode_from(shard_t *s, int from)
         size_t nb = 0, pos = 0;
         pump(&pp);
         H264E_clip_position(s->clip, &next_frame, &avail);
+        if (pp.failed) { printf("ERROR: upload failed: %s\n", H264E_last_error()); goto out; }
         if (avail <= next_frame)
         {
+            int starved;
             if (fd.error) { printf("ERROR: short read\n"); goto out; }
+            /* nothing to encode yet: fine while the reader or a copy is still at work -- but when the reader has finished, no
+             * buffer holds frames and no copy is in flight, nothing will ever arrive */
+            pthread_mutex_lock(&fd.mu);
+            starved = fd.eof && !fd.have[0] && !fd.have[1] && pp.inflight < 0;
+            pthread_mutex_unlock(&fd.mu);
+            if (starved) { printf("ERROR: input ended after %d of %d frames\n", avail, s->nframes); goto out; }
             usleep(200);
             continue;
         }
@@ -377,7 +400,7 @@ static void *shard_thread(void *arg)
 static int run_clip_mode(FILE *fout, int w, int h, long long total)
 {
     const size_t fsz = (size_t)w*h*3/2;
-    const int n = (int)((unsigned long long)total/fsz), gop = cmd.gop > 0 ? cmd.gop : n;
+    const int n = (int)((unsigned long long)total/fsz), gop = cmd.gop > 0 ? cmd.gop : n > 0 ? n : 1;
     const int ngop = (n + gop - 1)/gop;
     int nsh = cmd.gpus > 1 ? cmd.gpus : 1, k, g0 = 0, rc = 1, ndev = cmd.gpus > 1 ? H264E_device_count() : 1, f;
     shard_t *sh;
@@ -502,13 +525,17 @@ int main(int argc, char **argv)
      * one pipeline latency per frame) */
     if ((cmd.clip != 0 && cmd.max_frames) || cmd.gpus > 1)
     {
-        long long total;
-        int r;
-        fseeko(fin, 0, SEEK_END);
-        total = (long long)ftello(fin);
-        r = run_clip_mode(fout, w, h, total);
-        fclose(fin); fclose(fout);
-        return r;
+        /* the clip pipeline wants the frame count up front; an input that cannot say (a pipe, /dev/stdin) goes through the
+         * reference's own read-until-EOF loop below instead (T:584), and an empty file gives an empty stream like there (T:654) */
+        const long long total = fseeko(fin, 0, SEEK_END) ? -1 : (long long)ftello(fin);
+        if (total >= 0)
+        {
+            const int r = run_clip_mode(fout, w, h, total);
+            fclose(fin); fclose(fout);
+            return r;
+        }
+        if (cmd.gpus > 1) { printf("ERROR: --gpus needs a seekable input file\n"); return 1; }
+        clearerr(fin);
     }
 
     frame_size = w*h*3/2;

@@ -947,7 +947,11 @@ static int clip_put(H264E_clip_t *c, int first, int n, const uint8_t *i420, int 
     while (done < n)
     {
         const int slot = (first + done) % c->resident, run = imin(n - done, c->resident - slot);
-        if (async ? h264e_hip_upload_i420_async(c->pool, slot, run, i420 + fsz*(size_t)done) : h264e_hip_upload_i420(c->pool, slot, run, i420 + fsz*(size_t)done)) return -1;
+        if (async ? h264e_hip_upload_i420_async(c->pool, slot, run, i420 + fsz*(size_t)done) : h264e_hip_upload_i420(c->pool, slot, run, i420 + fsz*(size_t)done))
+        {
+            g_host_err[0] = 0;          /* H264E_last_error() -> the device layer's text */
+            return -1;
+        }
         done += run;
     }
     if (async) { if (first + n > c->pending_avail) c->pending_avail = first + n; }
@@ -973,8 +977,11 @@ int H264E_clip_upload_wait(H264E_clip_t *c)
 /* 1 = every asynchronous upload has landed (the frames now count as uploaded), 0 = still copying */
 int H264E_clip_upload_poll(H264E_clip_t *c)
 {
+    int busy;
     if (!c) return -1;
-    if (h264e_hip_upload_busy(c->pool)) return 0;
+    busy = h264e_hip_upload_busy(c->pool);
+    if (busy < 0) { g_host_err[0] = 0; return -1; }     /* the copy stream failed: H264E_last_error() carries the HIP text */
+    if (busy) return 0;
     if (c->pending_avail > c->avail) c->avail = c->pending_avail;
     return 1;
 }

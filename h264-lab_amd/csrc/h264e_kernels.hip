@@ -461,14 +461,22 @@ DEV void stage_selftest(StageLds &S, RowLds &L, int stage, const GLOBAL_AS uint8
         m.lambda_mv = k_lambda_mv_q4[a[9]];
         m.rv = R; m.rv.P = P8; m.rv.nmbx = 6; m.rv.nmby = 6;
         if (a[19]) { m.rv.has_win = 1; m.rv.win = (const lu8 *)L.win; m.rv.wx0 = 32 - WIN_M; m.rv.wy0 = 32 - WIN_M; wave_load_window(L.win, P8, m.rv.wx0, m.rv.wy0, 0); }
-        WAVE_FOR(l) { lds32_store(L.inp + 4*l, gload32((const gu8 *)in + 96*96 + 4*l)); lds32_store(L.test + 4*l, 0u); }
+        WAVE_FOR(l) { lds32_store(L.inp + 4*l, gload32((const gu8 *)in + 96*96 + 4*l)); lds32_store(L.gtest[0] + 4*l, 0u); }
         wave_sync();
-        mv32 mv = mvmk(a[4], a[5]);
         const rect_t range = { a[11], a[12], a[13], a[14] };
-        const int cost = diamond(L, m, a[0], a[1], mv, range, mvmk(a[6], a[7]), a[8], a[2], a[3], L.test + 16*a[1] + a[0]);
+        /* the search is lane-group code (wave.h): group a[20] runs it, the other three idle */
+        GRP_EACH(grp)
+        {
+            if (grp == (a[20] & 3))
+            {
+                mv32 mv = mvmk(a[4], a[5]);
+                const int cost = diamond_g(L, m, a[0], a[1], mv, range, mvmk(a[6], a[7]), a[8], a[2], a[3], L.gtest[0] + 16*a[1] + a[0], L.gscr);
+                L.gcost[0] = cost; L.gcost[1] = mvx(mv); L.gcost[2] = mvy(mv);
+            }
+        }
         wave_sync();
-        WAVE_FOR(l) { gstore32((gu8 *)out + 16 + 4*l, lds32(L.test + 4*l)); }
-        if (wave_lane() == 0) { oi[0] = cost; oi[1] = mvx(mv); oi[2] = mvy(mv); }
+        WAVE_FOR(l) { gstore32((gu8 *)out + 16 + 4*l, lds32(L.gtest[0] + 4*l)); }
+        if (wave_lane() == 0) { oi[0] = L.gcost[0]; oi[1] = L.gcost[1]; oi[2] = L.gcost[2]; }
     }
 }
 #ifndef H264E_EMU
@@ -602,6 +610,7 @@ struct h264e_hip_pool
     int *ref_sel;                        /* per chain */
     int ring_pos, pending;
     int profile, prof_launches;
+    int test_upload_fail_at, async_uploads;     /* fault injection (H264E_TEST_KNOBS): the n-th asynchronous upload of this pool fails */
     double prof_mb_ms, prof_splice_ms;
 #ifndef H264E_EMU
     hipStream_t stream;
@@ -738,10 +747,20 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     G.lim_x0 = G.lim_y0 = -14*4;                                    /* h264-lab.h:6322-6324, MV_GUARD 14 */
     G.lim_x1 = (G.W - 2)*4; G.lim_y1 = (G.H - 2)*4;
     G.row_words = G.nmbx*(H264E_ROW_BYTES_PER_MB/4);
-    /* knobs for the failure-path tests only: a tiny row bit buffer (overflow), a short spin bound and a row that never publishes */
-    if (getenv("H264E_TEST_ROW_BYTES_PER_MB")) { const int b = atoi(getenv("H264E_TEST_ROW_BYTES_PER_MB"))/4; G.row_words = G.nmbx*(b > 1 ? b : 1); }
-    G.spin_limit = getenv("H264E_TEST_SPIN_LIMIT") ? (unsigned)atol(getenv("H264E_TEST_SPIN_LIMIT")) : (1u << 24);
-    G.test_stall_row = getenv("H264E_TEST_STALL_ROW") ? atoi(getenv("H264E_TEST_STALL_ROW")) : -1;
+    /* knobs for the failure-path tests only: a tiny row bit buffer (overflow), a short spin bound, a row that never publishes, an
+     * asynchronous upload that fails.  They are looked at ONLY under the explicit switch H264E_TEST_KNOBS=1, so that a stray
+     * H264E_TEST_* variable inherited from somebody's environment cannot make a production encode fail. */
+    const int knobs = getenv("H264E_TEST_KNOBS") && atoi(getenv("H264E_TEST_KNOBS")) == 1;
+    G.spin_limit = 1u << 24;
+    G.test_stall_row = -1;
+    p->test_upload_fail_at = -1;
+    if (knobs)
+    {
+        if (getenv("H264E_TEST_ROW_BYTES_PER_MB")) { const int b = atoi(getenv("H264E_TEST_ROW_BYTES_PER_MB"))/4; G.row_words = G.nmbx*(b > 1 ? b : 1); }
+        if (getenv("H264E_TEST_SPIN_LIMIT")) G.spin_limit = (unsigned)atol(getenv("H264E_TEST_SPIN_LIMIT"));
+        if (getenv("H264E_TEST_STALL_ROW")) G.test_stall_row = atoi(getenv("H264E_TEST_STALL_ROW"));
+        if (getenv("H264E_TEST_UPLOAD_FAIL_AT")) p->test_upload_fail_at = atoi(getenv("H264E_TEST_UPLOAD_FAIL_AT"));
+    }
     p->frame_bytes = (size_t)width*height*3/2;
 #ifndef H264E_EMU
     int ndev = 0;
@@ -868,6 +887,7 @@ extern "C" int h264e_hip_upload_i420(h264e_hip_pool_t *p, int first, int nframes
 extern "C" int h264e_hip_upload_i420_async(h264e_hip_pool_t *p, int first, int nframes, const uint8_t *host)
 {
     if (!p || first < 0 || nframes < 0 || first + nframes > p->frames_resident) FAIL("upload_i420_async: bad range");
+    if (p->async_uploads++ == p->test_upload_fail_at) FAIL("upload_i420_async: injected failure (H264E_TEST_UPLOAD_FAIL_AT)");
 #ifdef H264E_EMU
     memcpy(p->clip + p->frame_bytes*(size_t)first, host, p->frame_bytes*(size_t)nframes);
 #else
@@ -895,7 +915,10 @@ extern "C" int h264e_hip_upload_busy(h264e_hip_pool_t *p)
 #else
     if (!p) return 0;
     (void)hipSetDevice(p->device);
-    return hipStreamQuery(p->copy_stream) == hipErrorNotReady;
+    const hipError_t e = hipStreamQuery(p->copy_stream);
+    if (e == hipErrorNotReady) return 1;
+    if (e != hipSuccess) FAIL("upload: %s", hipGetErrorString(e));      /* -1: the copy was lost, not finished */
+    return 0;
 #endif
 }
 

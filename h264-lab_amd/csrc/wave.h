@@ -80,6 +80,43 @@ DEV uint32_t sad4_u8(uint32_t a, uint32_t b, uint32_t acc)
 DEV int clz32(uint32_t v) { return __builtin_clz(v); }
 DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
+/* ---- lane groups (see the device build below): the emulation runs the four groups one after the other */
+#define GRP_EACH(g) for (int g = 0; g < 4; ++g)
+#ifdef H264E_EMU_REVERSE
+#define GRP_FOR(i) for (int i = 15; i >= 0; --i)
+#else
+#define GRP_FOR(i) for (int i = 0; i < 16; ++i)
+#endif
+template <class F> DEV int grp_sum(F f)
+{
+    int s = 0;
+    for (int i = 0; i < 16; ++i) s += f(i);
+    return s;
+}
+template <class F> DEV void grp_sum4(F f, int out[4])
+{
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (int i = 0; i < 16; ++i)
+    {
+        int v[4] = { 0, 0, 0, 0 };
+        f(i, v);
+        for (int k = 0; k < 4; ++k) out[k] += v[k];
+    }
+}
+template <class F> DEV void grp_sum8(F f, int out[8])
+{
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    for (int i = 0; i < 16; ++i)
+    {
+        int v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        f(i, v);
+        for (int k = 0; k < 8; ++k) out[k] += v[k];
+    }
+}
+template <class F> DEV void grp_eval4(F f, int out[4]) { for (int d = 0; d < 4; ++d) out[d] = f(d); }
+template <class F> DEV void grp_eval8(F f, int out[8]) { for (int d = 0; d < 8; ++d) out[d] = f(d); }
+DEV void grp_count(int *p) { *p += 1; }
+
 #else /* device build */
 
 #include <hip/hip_runtime.h>
@@ -138,6 +175,64 @@ template <class F> DEV uint64_t wave_ballot(F f) { return __ballot(f((int)thread
 DEV uint32_t sad4_u8(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
 DEV int clz32(uint32_t v) { return __clz((int)v); }
 DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+/*
+ * Lane groups: the wavefront as FOUR independent 16-lane groups (one DPP row each).  Inside GRP_EACH(g) { ... } every group runs
+ * its own control flow on its own values (plain per-lane registers that happen to agree inside a group; the hardware executes the
+ * groups' paths under the exec mask) -- the motion search runs the four partition types side by side this way, one group each,
+ * instead of one after the other.  Pixel work of a group fans out over its 16 lanes in GRP_FOR sections / the grp_sum reductions
+ * (DPP inside the row: every lane of the group receives the sum); nothing in a group section may use the wave-level primitives
+ * above (uni, wave_sum, LaneArr: they would mix the groups).
+ */
+#define GRP_EACH(g) for (int g = (int)threadIdx.x >> 4, _e1 = 1; _e1; _e1 = 0)
+#define GRP_FOR(i) for (int i = (int)threadIdx.x & 15, _g1 = 1; _g1; _g1 = 0)
+DEV int row_reduce_add(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);      /* quad_perm [1,0,3,2] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);      /* quad_perm [2,3,0,1] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);     /* row_half_mirror */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);     /* row_mirror */
+    return v;
+}
+template <class F> DEV int grp_sum(F f) { return row_reduce_add(f((int)threadIdx.x & 15)); }
+template <class F> DEV void grp_sum4(F f, int out[4])
+{
+    int v[4] = { 0, 0, 0, 0 };
+    f((int)threadIdx.x & 15, v);
+    /* sums stay below 2^16 for every caller (<= 256 samples x 255): two per register */
+    const int a = row_reduce_add(v[0] | (v[1] << 16)), b = row_reduce_add(v[2] | (v[3] << 16));
+    out[0] = a & 0xffff; out[1] = (int)((unsigned)a >> 16);
+    out[2] = b & 0xffff; out[3] = (int)((unsigned)b >> 16);
+}
+template <class F> DEV void grp_sum8(F f, int out[8])
+{
+    int v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    f((int)threadIdx.x & 15, v);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        const int a = row_reduce_add(v[2*k] | (v[2*k + 1] << 16));
+        out[2*k] = a & 0xffff; out[2*k + 1] = (int)((unsigned)a >> 16);
+    }
+}
+/* out[d] = f(d) for d = 0..3 (0..7): a group-uniform function evaluated once per lane (lane & 3 picks d) and handed round inside the
+ * quads, instead of four (eight) times in every lane */
+template <class F> DEV void grp_eval4(F f, int out[4])
+{
+    const int c = f((int)threadIdx.x & 3);
+    out[0] = __builtin_amdgcn_update_dpp(0, c, 0x00, 0xf, 0xf, true); out[1] = __builtin_amdgcn_update_dpp(0, c, 0x55, 0xf, 0xf, true);
+    out[2] = __builtin_amdgcn_update_dpp(0, c, 0xAA, 0xf, 0xf, true); out[3] = __builtin_amdgcn_update_dpp(0, c, 0xFF, 0xf, 0xf, true);
+}
+template <class F> DEV void grp_eval8(F f, int out[8])
+{
+    const int c0 = f((int)threadIdx.x & 3), c1 = f(4 + ((int)threadIdx.x & 3));
+    out[0] = __builtin_amdgcn_update_dpp(0, c0, 0x00, 0xf, 0xf, true); out[1] = __builtin_amdgcn_update_dpp(0, c0, 0x55, 0xf, 0xf, true);
+    out[2] = __builtin_amdgcn_update_dpp(0, c0, 0xAA, 0xf, 0xf, true); out[3] = __builtin_amdgcn_update_dpp(0, c0, 0xFF, 0xf, 0xf, true);
+    out[4] = __builtin_amdgcn_update_dpp(0, c1, 0x00, 0xf, 0xf, true); out[5] = __builtin_amdgcn_update_dpp(0, c1, 0x55, 0xf, 0xf, true);
+    out[6] = __builtin_amdgcn_update_dpp(0, c1, 0xAA, 0xf, 0xf, true); out[7] = __builtin_amdgcn_update_dpp(0, c1, 0xFF, 0xf, 0xf, true);
+}
+/* a statistics counter in LDS, bumped once per group */
+DEV void grp_count(int *p) { if (((int)threadIdx.x & 15) == 0) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
 
 /* diagnostic build only (-DH264E_STAMPS): cycle stamps per pipeline phase, accumulated in LDS (never in the product) */

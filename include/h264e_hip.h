@@ -98,7 +98,7 @@ int  h264e_hip_upload_i420(h264e_hip_pool_t *pool, int first, int nframes, const
  * stream; h264e_hip_upload_wait() blocks until every such copy has landed */
 int  h264e_hip_upload_i420_async(h264e_hip_pool_t *pool, int first, int nframes, const uint8_t *pinned_i420);
 int  h264e_hip_upload_wait(h264e_hip_pool_t *pool);
-int  h264e_hip_upload_busy(h264e_hip_pool_t *pool);         /* 1 while such a copy is still in flight */
+int  h264e_hip_upload_busy(h264e_hip_pool_t *pool);         /* 1 while such a copy is still in flight, 0 when all have landed, -1 when the copy stream failed */
 void *h264e_hip_host_alloc(size_t bytes);
 void h264e_hip_host_free(void *p);
 /* one frame from three planes with arbitrary strides (the H264E_io_yuv_t of the drop-in API) */

@@ -10,7 +10,8 @@
  *   H264E_encode          replaces h264-lab.h:6654-6861   (macroblock loop runs as HIP kernels, include/h264e_hip.h)
  *   H264E_set_vbv_state   replaces h264-lab.h:6898-6913
  *
- * Scope: AVC baseline, key and P frames, one reference frame, single slice per frame,
+ * Scope: AVC baseline, key and P frames, one reference frame, one slice per frame or N
+ * row-band slices (H264E_set_slices / H264E_clip_param_t.slices: the reference's H264E_MAX_THREADS build),
  * constant QP or frame-level rate control.  Long-term reference frame types, SVC layers, the temporal
  * denoiser, MB-level rate control and NALU-size slicing answer H264E_STATUS_BAD_PARAMETER at init /
  * H264E_STATUS_BAD_FRAME_TYPE at encode instead of silently producing a different stream.
@@ -76,7 +77,7 @@ typedef struct H264E_run_param_tag
     int desired_frame_bytes;
     int qp_min;
     int qp_max;
-    int desired_nalu_bytes;                 /* must be 0 (one slice per frame) */
+    int desired_nalu_bytes;                 /* must be 0: byte-budget slicing (h264-lab.h:6418-6430) is refused; row-band slices: H264E_set_slices() */
     void (*nalu_callback)(const unsigned char *nalu_data, int sizeof_nalu_data, void *token);
     void *nalu_callback_token;
 } H264E_run_param_t;
@@ -123,7 +124,8 @@ typedef struct
     int width, height, gop, qp, speed;
     int vbv_size_bytes;                     /* SPS level only */
     int device;
-    int max_chains;                         /* frames in flight per launch (0 = default 96) */
+    int max_chains;                         /* cap of the slot ring (frame f lives in slot f % K; K - 1 = most frames one launch can hold); 0 = sized by the
+                                               memory budget: 622 slots at 1080p, 162 at 4K, 40 at 8K, at most 1024 */
     int first_idr_pic_id_state;             /* enc->next_idr_pic_id before the first frame (0 for a fresh stream) */
     int32_t mv_clusters_in[2];              /* enc->mv_clusters before the first frame (0,0 for a fresh stream) */
     int slices;                             /* row-band slices per frame: 0 / 1 = one; N = the reference's H264E_MAX_THREADS build with --threads N */

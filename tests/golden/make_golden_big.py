@@ -45,6 +45,11 @@ CASES = {
     # tests/clips.py `scene` (numpy generator): static background, occluding sprites, a scene cut at frame 45 whose P frame is mostly intra
     "scene_1080p_90": (1920, 1080, 90, "--qp 28 --gop 30", REF, "scene"),
     "scene_1080p_60_thr4": (1920, 1080, 60, "--qp 30 --gop 30 --threads 4", REF_THR, "scene"),
+    # 4K / 8K at lengths that reach the abort / relaunch path, slot reuse and GOP boundaries (round-2 VERDICT, weak item 1)
+    "4k_240": (3840, 2160, 240, "--qp 26 --gop 30", REF),                      # configs[3] geometry, 8 GOPs, ~10 relaunches on the GPU
+    "4k_240_thr8": (3840, 2160, 240, "--qp 26 --gop 30 --threads 8", REF_THR),
+    "8k_35": (7680, 4320, 35, "--qp 26 --gop 30", REF),                        # crosses a GOP boundary at 8K
+    "8k_30_thr2_kbps": (7680, 4320, 30, "--kbps 60000 --gop 30 --threads 2", REF_THR),    # configs[4] over a full GOP
 }
 
 

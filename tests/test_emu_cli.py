@@ -79,3 +79,47 @@ def test_gpus_option_shards_one_stream(tmp_path, name, w, h, n, flags, kw, gpus,
     last = r.stderr.strip().splitlines()[-1]
     assert ("GOP-sharded over %d clip encoders" % gpus) in last
     assert (" 0 frames encoded again" not in last) == redo
+
+
+def test_refused_options_empty_input_and_upload_failure(tmp_path):
+    """the CLI's error paths, none of which may hang or write a different stream: options of the reference that this encoder
+    refuses (minih264e_test.c:135 --gen, :163 --denoise) -> exit 1 and no output file; an empty input and --gop 0 -> an empty
+    stream and exit 0 like the reference's read loop (minih264e_test.c:654); a failed asynchronous upload in the clip pipeline
+    (injected) -> error text and a non-zero exit in bounded time; a non-seekable input -> the frame-at-a-time loop"""
+    w, h, n = 176, 144, 6
+    c = clips.make("synth", w, h, n)
+    yuv = tmp_path / ("app_%dx%d.yuv" % (w, h))
+    c.tofile(yuv)
+    out = tmp_path / "o.264"
+    for opt in ("--denoise", "--gen"):
+        r = subprocess.run([APP, "--input", str(yuv), "--output", str(out), opt, "x", "--qp", "26"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and "not supported" in r.stdout and not out.exists()
+    empty = tmp_path / ("empty_%dx%d.yuv" % (w, h))
+    empty.write_bytes(b"")
+    for flags in (["--gop", "0"], ["--gop", "5"], ["--gop", "0", "--clip", "0"]):
+        r = subprocess.run([APP, "--input", str(empty), "--output", str(out)] + flags, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and out.read_bytes() == b"", r.stdout + r.stderr
+    want, _ = oracle_lib.encode_clip(c, w, h, gop=0, qp=26)
+    r = subprocess.run([APP, "--input", str(yuv), "--output", str(out), "--gop", "0", "--qp", "26"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and out.read_bytes() == want
+    # the second asynchronous upload fails: the run ends with the device layer's message instead of waiting for frames forever
+    fsz = w * h * 3 // 2
+    env = dict(os.environ, H264E_TEST_KNOBS="1", H264E_TEST_UPLOAD_FAIL_AT="1", H264E_APP_STAGE_KB=str(fsz * 2 // 1024 + 1), H264E_APP_RING_KB=str(fsz * 8 // 1024))
+    r = subprocess.run([APP, "--input", str(yuv), "--output", str(out), "--qp", "26"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "upload failed" in r.stdout and "injected failure" in r.stdout, r.stdout + r.stderr
+    # without the explicit switch the knob is ignored
+    env.pop("H264E_TEST_KNOBS")
+    r = subprocess.run([APP, "--input", str(yuv), "--output", str(out), "--qp", "26", "--gop", "30"], env=env, capture_output=True, text=True, timeout=120)
+    want30, _ = oracle_lib.encode_clip(c, w, h, gop=30, qp=26)
+    assert r.returncode == 0 and out.read_bytes() == want30
+    # a pipe has no length: the reference's read-until-EOF loop takes over
+    with open(yuv, "rb") as f:
+        r = subprocess.run("cat | %s --input /dev/stdin_%dx%d --output %s --qp 26 --gop 30" % (APP, w, h, out), shell=True, stdin=f, capture_output=True, text=True, timeout=120)
+    assert "cant open input file" in r.stdout      # the size lives in the file NAME (guess_format): /dev/stdin_176x144 does not exist
+    link = tmp_path / ("pipe_%dx%d.yuv" % (w, h))
+    os.mkfifo(link)
+    p = subprocess.Popen([APP, "--input", str(link), "--output", str(out), "--qp", "26", "--gop", "30"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    with open(link, "wb") as f:
+        f.write(c.tobytes())
+    so, se = p.communicate(timeout=120)
+    assert p.returncode == 0 and out.read_bytes() == want30, so.decode() + se.decode()

@@ -180,6 +180,7 @@ def test_frames_larger_than_the_host_mirror_are_fetched(monkeypatch):
 def test_row_bit_buffer_overflow_is_reported(monkeypatch):
     """a 16-byte-per-macroblock row bit buffer (test knob) cannot hold QP 10 noise: both APIs fail with an error instead of a
     truncated stream (the GPU run of this lives in tests/test_gpu_failures.py together with the stuck-producer case)"""
+    monkeypatch.setenv("H264E_TEST_KNOBS", "1")
     monkeypatch.setenv("H264E_TEST_ROW_BYTES_PER_MB", "16")
     P = pkg.load_pkg()
     c = clips.make("noise", 176, 144, 2)

@@ -22,6 +22,7 @@ def P():
 def test_stuck_producer_is_reported_not_hung(P, monkeypatch):
     """row 3 of the first frame exits without publishing: row 4 spins until the (shortened) bound expires, poisons its counter and
     raises the launch's error flag; every row below and the finalizer stop on the poison; the API returns an error in bounded time"""
+    monkeypatch.setenv("H264E_TEST_KNOBS", "1")
     monkeypatch.setenv("H264E_TEST_STALL_ROW", "3")
     monkeypatch.setenv("H264E_TEST_SPIN_LIMIT", "20000")
     w, h, n = 352, 288, 4
@@ -49,6 +50,7 @@ def test_stuck_producer_is_reported_not_hung(P, monkeypatch):
 def test_row_bit_buffer_overflow_is_reported(P, monkeypatch):
     """a 16-byte-per-macroblock row bit buffer cannot hold QP 10 noise: the kernel flags the overflow instead of writing past the
     buffer, and both APIs fail with the reference-style error instead of returning a truncated stream"""
+    monkeypatch.setenv("H264E_TEST_KNOBS", "1")
     monkeypatch.setenv("H264E_TEST_ROW_BYTES_PER_MB", "16")
     w, h, n = 176, 144, 2
     c = clips.make("noise", w, h, n)

@@ -222,9 +222,10 @@ def _check_stages(run):
         nb = (c["nbits"] + 7) // 8
         assert words[:nb] == _b(c["bits"])[:nb], ("cavlc bits", c)
     for window in (0, 1):
-        for c in FIX["diamond"]:
+        for ci, c in enumerate(FIX["diamond"]):
             ref = _b(FIX["diamond_refs"][c["ref"]]["pic"])
-            args = [c["px"], c["py"], c["w"], c["h"]] + c["mv_in"] + c["mv_pred"] + [c["min_sad_in"], c["qp"], c["speed"]] + c["range"] + c["limit"] + [window]
+            # args[20]: which 16-lane group of the wave runs the search (it is lane-group code: every group must give the same answer)
+            args = [c["px"], c["py"], c["w"], c["h"]] + c["mv_in"] + c["mv_pred"] + [c["min_sad_in"], c["qp"], c["speed"]] + c["range"] + c["limit"] + [window, ci % 4]
             r = run(8, ref + _b(c["cur"]), args, 16 + 256)
             cost, mx, my = np.frombuffer(r[:12], np.int32)
             assert (cost, [mx, my]) == (c["cost"], c["mv"]), ("motion search", window, {k: v for k, v in c.items() if k not in ("cur", "pred")})
