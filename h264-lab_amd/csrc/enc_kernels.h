@@ -803,7 +803,7 @@ DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_
     {
         /* same computation with the rows and their SADs kept in registers: lane 4k + y holds row y of mode slot k, the four
          * row SADs of a slot are added inside the quad (DPP) and read with v_readlane -- no LDS round trips for the choice */
-        const int l = (int)threadIdx.x, k = l >> 2, y = l & 3;
+        const int l = LANE, k = l >> 2, y = l & 3;
         uint32_t row = 0;
         int qs = 0;
         if (k < 9)
@@ -1081,7 +1081,7 @@ DEV int cavlc_block(BitW &b, const CavlcTab &ct, const int16_t *base, int first,
 #else
     /* one LDS read for the whole block: lane p holds coefficient p; the scalar code below picks coefficients with
      * v_readlane instead of one LDS round trip each */
-    const int cv = (int)threadIdx.x < maxn ? (int)base[first + (int)threadIdx.x] : 0;
+    const int cv = LANE < maxn ? (int)base[first + LANE] : 0;
     mask = (uint32_t)__ballot(cv != 0);
 #define COEF(p) __builtin_amdgcn_readlane(cv, (p))
 #endif

@@ -20,10 +20,35 @@ struct GCtx { mv32 mv_left[4], mv_tl[4], mv_top[8]; };
 #define GSCR_OFF(t) ((t) == 0 ? 0 : (t) == 1 ? 1024 : (t) == 2 ? 1536 : 2048)
 #define GSCR_BYTES 2304
 
+/*
+ * What one macroblock hands from the SEARCH side of the pipeline (neighbour records + input + motion search) to the RECONSTRUCTION
+ * side (intra decisions, transform / CAVLC, deblocking, stores).  Two of them per row (macroblock x uses mb[x & 1]): with two
+ * wavefronts per row (h264e_kernels.hip) the search wave fills the buffer of macroblock x + 1 while the reconstruction wave still
+ * works from the buffer of x.
+ */
+struct MbBuf
+{
+    alignas(16) uint8_t inp[256];
+    alignas(16) uint8_t inp_c[128];
+    alignas(16) uint8_t pred[256];                  /* luma prediction of the decision so far (inter, then 16x16 intra when that wins) */
+    alignas(4) uint8_t pix_top[36];                 /* 16 Y, 8 U, 8 V of the macroblock above + 4 Y of the one above-right */
+    alignas(4) uint8_t ptop[96];                    /* pending bottom lines of the macroblock above (h264e_mbpend_t), fetched with its record */
+    mv32 mv_top[8];
+    uint8_t nnz_top[8];
+    int8_t i4_top[4];
+    uint32_t df_nz_top;
+    int top_type, top_qp;
+    mv32 mv[16], mvd[16];
+    /* result of the inter decision (H:5283-5524): type -1 skip, 0..3 partition type; an I slice leaves type 0, cost 0x7fffffff */
+    int type, cost, used_cand;
+    mv32 mv_skip_pred;
+};
+
 struct RowLds
 {
-    /* ---- carried from macroblock to macroblock along the row */
+    /* ---- search side: predictor context carried along the row (written by the decision of macroblock x, read by the search of x + 1) */
     mv32 mv_left[4], mv_tl[4];
+    /* ---- reconstruction side: carried from macroblock to macroblock along the row */
     uint8_t nnz_left[8];
     int8_t i4_left[4];
     alignas(4) uint8_t pix_left[32];
@@ -33,42 +58,37 @@ struct RowLds
     int left_type, left_qp;
     alignas(4) uint8_t strip_y[16*4];               /* deblocked columns 12..15 of the left macroblock (luma), 6..7 (chroma) */
     alignas(4) uint8_t strip_c[2][8*4];             /* columns 4..7 of the left macroblock's chroma (final except column 7) */
-    alignas(4) uint8_t ptop[96];                    /* pending bottom lines of the macroblock above (h264e_mbpend_t), fetched with its record */
-    alignas(4) uint8_t trec[72];                    /* staged record of the macroblock above (+ 8 bytes of the one above-right) */
     alignas(4) uint8_t brec[64];                    /* record of this macroblock for the row below, assembled here */
     BitW bw;
     int skip_run, lead_skips, coded_any;
-    int far_reads;                                  /* reference accesses of this row that left the valid window */
+    /* ---- both sides */
+    int far_reads[2];                               /* reference accesses of this row that left the valid window (search / reconstruction side) */
+    int far_fail[2];                                /* a dynamic wait behind such an access gave up (enc_kernels.h rv_wait_rect): -1 expired, -2 producer aborted */
     int16_t slice_row[H264E_MAX_SLICES + 2];       /* this frame's slice start rows (copy of the task's) */
-    int far_fail;                                   /* a dynamic wait behind such an access gave up (enc_kernels.h rv_wait_rect): -1 expired, -2 producer aborted */
-    unsigned long long prof[32], prof_last, prof_c0, prof_w0;
+    unsigned long long prof[2][32], prof_last[2], prof_c0, prof_w0;     /* -DH264E_STAMPS diagnostic build only */
+    /* hand-off words of the two-wave pipeline (h264e_kernels.hip): monotonic counters "macroblocks done" per stage, and a stop code */
+    int f_loaded, f_noskip, f_inter, f_decided, f_wdone, f_stop;
 
-    /* ---- per macroblock */
-    mv32 mv_top[8];
-    uint8_t nnz_top[8];
-    int8_t i4_top[4];
-    uint32_t df_nz_top;
-    int top_type, top_qp;
-    alignas(4) uint8_t pix_top[36];                 /* 16 Y, 8 U, 8 V of the macroblock above + 4 Y of the one above-right */
-    mv32 mv[16], mvd[16], part_mv[4][4], part_mvd[4][4];
+    MbBuf mb[2];
+
+    /* ---- search side, per macroblock */
+    alignas(4) uint8_t trec[72];                    /* staged record of the macroblock above (+ 8 bytes of the one above-right) */
+    mv32 part_mv[4][4], part_mvd[4][4];
     GCtx gctx[4];                                   /* the motion search's predictor context, one copy per partition type (lane group) */
     int gcost[4], gnum[4];                          /* cost and number of partitions of every partition type searched */
+    alignas(16) uint8_t win[WIN_W*WIN_STRIDE + 16];  /* reference luma window around the current macroblock */
+    alignas(16) uint8_t skip_pred[256];
+    alignas(16) uint8_t skip_pred_c[128];           /* chroma of the early-skip test (the reconstruction side predicts chroma again for itself) */
+    alignas(16) uint8_t gtest[4][256];              /* prediction of every partition type searched */
+    alignas(16) uint8_t gscr[GSCR_BYTES];           /* sub-pel search: the full-sample block and the three half-sample planes of the partition a group works on */
+
+    /* ---- reconstruction side, per macroblock */
     int8_t i4_mode[16];
     alignas(4) uint8_t bs[32];
     I4Scratch i4s;
-    CavlcTab cavlc;
-    DfTab dftab;
-    int qconst[6];                                  /* this frame's decision constants: lambda_mv, lambda_q4, skip_thr, skip_thr_i4, lambda_i4, lambda_i16 */
     uint8_t nzctx[12];
-    uint16_t qdat[2][42];                           /* this frame's quantizer tables, copied from the task */
-    alignas(16) uint8_t win[WIN_W*WIN_STRIDE + 16];  /* reference luma window around the current macroblock */
-    alignas(16) uint8_t inp[256];
-    alignas(16) uint8_t inp_c[128];
-    alignas(16) uint8_t pred[256];
     alignas(16) uint8_t pred_c[128];
-    alignas(16) uint8_t skip_pred[256];
-    alignas(16) uint8_t gtest[4][256];              /* prediction of every partition type searched (gtest[0] doubles as scratch of the 16x16 intra test) */
-    alignas(16) uint8_t gscr[GSCR_BYTES];           /* sub-pel search: the full-sample block and the three half-sample planes of the partition a group works on */
+    alignas(16) uint8_t i16pred[256];               /* 16x16 intra prediction under test */
     alignas(16) uint8_t tt[256];
     alignas(16) uint8_t i4rec[17*24];               /* intra 4x4 working picture: row 0 / column 0 = neighbours */
     alignas(16) uint8_t ytile[20*YT_STRIDE];
@@ -76,6 +96,12 @@ struct RowLds
     alignas(16) qblk_t qy[16];
     qblk_t qu[4], qv[4];
     int16_t dcy[16], dcu[4], dcv[4], lev_dcy[16], lev_dcu[4], lev_dcv[4];
+
+    /* ---- tables of the frame (read-only after row_begin) */
+    CavlcTab cavlc;
+    DfTab dftab;
+    int qconst[6];                                  /* this frame's decision constants: lambda_mv, lambda_q4, skip_thr, skip_thr_i4, lambda_i4, lambda_i16 */
+    uint16_t qdat[2][42];                           /* this frame's quantizer tables, copied from the task */
 };
 
 struct MbCtx
@@ -119,7 +145,7 @@ DEV void mvp_put_arr(mv32 *mv_left, mv32 *mv_tl, mv32 *mv_top, int x, int y, int
     for (int i = 0; i < h; i++) mv_left[y + i] = mv;
     for (int i = 0; i < w; i++) mv_top[x + i] = mv;
 }
-DEV void mvp_put(RowLds &L, int x, int y, int w, int h, mv32 mv) { mvp_put_arr(L.mv_left, L.mv_tl, L.mv_top, x, y, w, h, mv); }
+DEV void mvp_put(RowLds &L, MbBuf &B, int x, int y, int w, int h, mv32 mv) { mvp_put_arr(L.mv_left, L.mv_tl, B.mv_top, x, y, w, h, mv); }
 
 /* H:3720-3872 me_mv_medianpredictor_get */
 DEV mv32 mvp_get_arr(const mv32 *mv_left, const mv32 *mv_tl, const mv32 *mv_top, int flag, int x, int y, int w, int h)
@@ -168,7 +194,7 @@ DEV mv32 mvp_get_arr(const mv32 *mv_left, const mv32 *mv_tl, const mv32 *mv_top,
 #undef OK
     return ret;
 }
-DEV mv32 mvp_get(const RowLds &L, const MbCtx &m, int x, int y, int w, int h) { return (mv32)uni(mvp_get_arr(L.mv_left, L.mv_tl, L.mv_top, m.avail, x, y, w, h)); }
+DEV mv32 mvp_get(const RowLds &L, const MbBuf &B, const MbCtx &m, int x, int y, int w, int h) { return (mv32)uni(mvp_get_arr(L.mv_left, L.mv_tl, B.mv_top, m.avail, x, y, w, h)); }
 
 /* ------------------------------------------------------------------ motion search */
 
@@ -192,10 +218,10 @@ DEV void set_range(mv32 &pnt, rect_t &range, const rect_t &limit, int mby_q)
  * each, so every "scalar" of this function is a per-lane value that agrees inside the group; the block's dwords are dealt to the
  * group's lanes 16 per pass.  scr = the group's sub-pel scratch (4 planes of w*h bytes).
  */
-DEV int diamond_g(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rect_t &range, mv32 mv_pred, int min_sad, int w, int h, uint8_t *dst, uint8_t *scr)
+DEV int diamond_g(RowLds &L, const MbBuf &B, const MbCtx &m, int px, int py, mv32 &mv, const rect_t &range, mv32 mv_pred, int min_sad, int w, int h, uint8_t *dst, uint8_t *scr)
 {
     const RefView &R = m.rv;
-    const uint8_t *b = L.inp + 16*py + px;
+    const uint8_t *b = B.inp + 16*py + px;
     /* the reference's uint16 cache[8]: four 16-bit fields each in `cur` (neighbours of the centre) and `prv` */
     uint64_t cur, prv;
 #define CGET(c, d) ((uint32_t)((c) >> (16*(d))) & 0xffffu)
@@ -401,7 +427,7 @@ DEV int diamond_g(RowLds &L, const MbCtx &m, int px, int py, mv32 &mv, const rec
  * are independent of each other: every one starts from the macroblock's predictor context (H:3646-3671).  Leaves the type's cost in
  * L.gcost[t], its vectors in L.part_mv[t] / L.part_mvd[t] and its prediction in L.gtest[t].
  */
-DEV void search_type(RowLds &L, const MbCtx &m, int t, mv32 mv_best, int sad_best0, const rect_t &lim)
+DEV void search_type(RowLds &L, const MbBuf &B, const MbCtx &m, int t, mv32 mv_best, int sad_best0, const rect_t &lim)
 {
     GCtx &X = L.gctx[t];
     int imv = 0, part_sad = MUL_LAMBDA(t == 0 ? 1 : t == 3 ? 12 : 4, m.lambda_q4);
@@ -419,10 +445,10 @@ DEV void search_type(RowLds &L, const MbCtx &m, int t, mv32 mv_best, int sad_bes
         {
             mvabs = mvround(mb_abs(m, mvp));
             set_range(mvabs, range, lim, m.y*64 + py*4);
-            sad_best = grp_sad_ref(m.rv, px + (mvx(mvabs) >> 2), py + (mvy(mvabs) >> 2), L.inp + 16*py + px, w, h)
+            sad_best = grp_sad_ref(m.rv, px + (mvx(mvabs) >> 2), py + (mvy(mvabs) >> 2), B.inp + 16*py + px, w, h)
                      + mv_cost(m, mvabs, mb_abs(m, mvp));
         }
-        part_sad += diamond_g(L, m, px, py, mvabs, range, mb_abs(m, mvp), sad_best, w, h, test + 16*py + px, scr);
+        part_sad += diamond_g(L, B, m, px, py, mvabs, range, mb_abs(m, mvp), sad_best, w, h, test + 16*py + px, scr);
         const mv32 mv = mvsub(mvabs, mvmk(m.x*64, m.y*64));
         L.part_mvd[t][imv] = mvsub(mv, mvp);
         L.part_mv[t][imv++] = mv;
@@ -451,13 +477,13 @@ DEV void partition_hints(const int sad[4], int mode[4])
 }
 
 /* H:4915-4947 interpolate_chroma: every partition of the current type, both planes -> L.pred_c */
-DEV void predict_chroma_inter(RowLds &L, const MbCtx &m)
+DEV void predict_chroma_inter(const MbBuf &B, const MbCtx &m, uint8_t *pred_c)
 {
     int w = (m.type & 2) ? 4 : 8, h = (m.type & 1) ? 4 : 8, part = 0, x = 0, y = 0;
     if (m.type == -1) w = h = 8;
     for (;; part++)
     {
-        wave_interp_chroma(m.rv, m.ref[1], m.ref[2], x, y, mb_abs(m, L.mv[part]), w, h, L.pred_c + 16*y + x);
+        wave_interp_chroma(m.rv, m.ref[1], m.ref[2], x, y, mb_abs(m, B.mv[part]), w, h, pred_c + 16*y + x);
         x = (x + w) & 7;
         if (!x)
         {
@@ -474,7 +500,7 @@ DEV void predict_chroma_inter(RowLds &L, const MbCtx &m)
  * copy before the SAD is taken -- first by U, then again by V.  Reproduced arithmetically:
  * row r < 4 of plane c is compared with input row 2r + c instead of the prediction.
  */
-DEV int skip_chroma_ok(const RowLds &L, const MbCtx &m)
+DEV int skip_chroma_ok(const MbBuf &B, const MbCtx &m, const uint8_t *pred_c)
 {
     const int thr = m.skip_thr;
     for (int c = 0; c < 2; c++)
@@ -482,8 +508,8 @@ DEV int skip_chroma_ok(const RowLds &L, const MbCtx &m)
         int sad = wave_sum([&](int l) -> int {
             if (l >= 16) return 0;
             int r = l >> 1, g = l & 1;
-            uint32_t a = lds32(L.inp_c + 16*r + 8*c + 4*g);
-            uint32_t p = (m.cropped && r < 4) ? lds32(L.inp_c + 16*(2*r + c) + 8*c + 4*g) : lds32(L.pred_c + 16*r + 8*c + 4*g);
+            uint32_t a = lds32(B.inp_c + 16*r + 8*c + 4*g);
+            uint32_t p = (m.cropped && r < 4) ? lds32(B.inp_c + 16*(2*r + c) + 8*c + 4*g) : lds32(pred_c + 16*r + 8*c + 4*g);
             return (int)sad4_u8(a, p, 0);
         });
         if (sad >= thr) return 0;
@@ -492,7 +518,7 @@ DEV int skip_chroma_ok(const RowLds &L, const MbCtx &m)
 }
 
 /* H:5283-5524 inter_choose_mode */
-DEV void inter_choose(RowLds &L, MbCtx &m)
+template <class HOOK> DEV void inter_choose(RowLds &L, MbBuf &B, MbCtx &m, HOOK noskip)
 {
     int prefer[4] = { 1, 0, 0, 0 };      /* constant indices only after unrolling: stays in registers */
     const RefView &R = m.rv;
@@ -505,31 +531,25 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
 #endif
 
     /* H:3877-3890 skip predictor */
-    const mv32 mv_pred16 = mvp_get(L, m, 0, 0, 4, 4);
+    const mv32 mv_pred16 = mvp_get(L, B, m, 0, 0, 4, 4);
     m.mv_skip_pred = 0;
-    if (!(~m.avail & (AV_L | AV_T)) && L.mv_left[0] != 0 && L.mv_top[0] != 0) m.mv_skip_pred = mv_pred16;
+    if (!(~m.avail & (AV_L | AV_T)) && L.mv_left[0] != 0 && B.mv_top[0] != 0) m.mv_skip_pred = mv_pred16;
     const mv32 mv_skip = m.mv_skip_pred, mv_skip_a = mb_abs(m, mv_skip);
-
-    for (int i = 0; i < 4; i++)
-    {
-        L.df_mv[4 + 5*i] = L.mv_left[i];
-        L.df_mv[i] = L.mv_top[i];
-    }
 
     STAMP(L, 2);
     if (in_rect(mv_skip_a, mv_qlimit(m)))
     {
         wave_interp_luma(R, 0, 0, mv_skip_a, 16, 16, L.skip_pred);
-        sad_skip = wave_sad_lds_q(L.inp, L.skip_pred, sad4);
+        sad_skip = wave_sad_lds_q(B.inp, L.skip_pred, sad4);
         if (imax(imax(sad4[0], sad4[1]), imax(sad4[2], sad4[3])) < m.skip_thr)
         {
             m.type = -1;
-            L.mv[0] = mv_skip;
+            B.mv[0] = mv_skip;
             m.cost = 0;
-            predict_chroma_inter(L, m);
-            if (skip_chroma_ok(L, m))
+            predict_chroma_inter(B, m, L.skip_pred_c);
+            if (skip_chroma_ok(B, m, L.skip_pred_c))
             {
-                wave_copy_wh(L.pred, L.skip_pred, 16, 16);
+                wave_copy_wh(B.pred, L.skip_pred, 16, 16);
                 return;
             }
         }
@@ -543,14 +563,15 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
             j = 1;
         }
     }
+    noskip();                   /* not an early skip: the intra candidates will be wanted */
 
     STAMP(L, 3);
     m.used_cand = 1;
     cand.set(ncand++, mv_pred16);
     cand.set(ncand++, 0);                                                    /* H:3895-3914 */
     if ((m.avail & AV_L) && L.mv_left[0] != MV_NA) cand.set(ncand++, L.mv_left[0]);
-    if ((m.avail & AV_T) && L.mv_top[0] != MV_NA) cand.set(ncand++, L.mv_top[0]);
-    if ((m.avail & AV_TR) && L.mv_top[4] != MV_NA) cand.set(ncand++, L.mv_top[4]);
+    if ((m.avail & AV_T) && B.mv_top[0] != MV_NA) cand.set(ncand++, B.mv_top[0]);
+    if ((m.avail & AV_TR) && B.mv_top[4] != MV_NA) cand.set(ncand++, B.mv_top[4]);
     if (m.x <= 0) cand.set(ncand++, mvmk(8*4, 0));
     if (m.y <= 0) cand.set(ncand++, mvmk(0, 8*4));
     {
@@ -584,7 +605,7 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
         if (in_rect(va, lim))
         {
             int c = mv_cost(m, cj, mv_pred16), s4[4];
-            sad = wave_sad_ref_q(R, bx + (mvx(cj) >> 2), by + (mvy(cj) >> 2), L.inp, s4);
+            sad = wave_sad_ref_q(R, bx + (mvx(cj) >> 2), by + (mvy(cj) >> 2), B.inp, s4);
             if (m.speed < 1) partition_hints(s4, prefer);
             if (sad + c < sad_best + cand_cost_best)
             {
@@ -605,12 +626,12 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
     {
         const int i = l & 15;
         mv32 *c = &L.gctx[l >> 4].mv_left[0];              /* the 16 words of a GCtx: left[4], tl[4], top[8] */
-        c[i] = i < 4 ? L.mv_left[i] : i < 8 ? L.mv_tl[i - 4] : i < 13 ? L.mv_top[i - 8] : 0;
+        c[i] = i < 4 ? L.mv_left[i] : i < 8 ? L.mv_tl[i - 4] : i < 13 ? B.mv_top[i - 8] : 0;
     }
     wave_sync();
     GRP_EACH(t)
     {
-        if ((types >> t) & 1) search_type(L, m, t, mv_best, sad_best, lim);
+        if ((types >> t) & 1) search_type(L, B, m, t, mv_best, sad_best, lim);
     }
     wave_sync();
     STAMP(L, 5);
@@ -622,26 +643,27 @@ DEV void inter_choose(RowLds &L, MbCtx &m)
             const int c = uni(L.gcost[t]);
             if (c < m.cost) { m.cost = c; m.type = t; best_n = uni(L.gnum[t]); }
         }
-    wave_copy_wh(L.pred, L.gtest[m.type], 16, 16);
-    for (int i = 0; i < best_n; i++) { L.mv[i] = L.part_mv[m.type][i]; L.mvd[i] = L.part_mvd[m.type][i]; }
+    wave_copy_wh(B.pred, L.gtest[m.type], 16, 16);
+    for (int i = 0; i < best_n; i++) { B.mv[i] = L.part_mv[m.type][i]; B.mvd[i] = L.part_mvd[m.type][i]; }
     wave_sync();
 
     if (m.cost > sad_skip)
     {
         m.type = 0;
         m.cost = sad_skip + mv_cost(m, mv_skip, mv_pred16);
-        L.mv[0] = mv_skip;
-        L.mvd[0] = mvsub(mv_skip, mv_pred16);
-        wave_copy_wh(L.pred, L.skip_pred, 16, 16);
+        B.mv[0] = mv_skip;
+        B.mvd[0] = mvsub(mv_skip, mv_pred16);
+        wave_copy_wh(B.pred, L.skip_pred, 16, 16);
     }
 }
 
 /* ------------------------------------------------------------------ intra decisions */
 
-/* H:4838-4858 intra_estimate_16x16 + H:4876-4896 intra_choose_16x16 */
-DEV void intra16_choose(RowLds &L, MbCtx &m)
+/* H:4838-4858 intra_estimate_16x16 + H:4876-4896 intra_choose_16x16: picks the mode (m.i16_mode), leaves its prediction in L.i16pred and
+ * returns its cost; the caller takes it when that is below the best cost so far (intra_merge) */
+DEV int intra16_cost(RowLds &L, const MbBuf &B, MbCtx &m)
 {
-    const uint8_t *p = L.inp;
+    const uint8_t *p = B.inp;
     const int v = m.avail & 3;             /* H:4840 mode_i16x16_valid: bit 0 = vertical allowed (top), bit 1 = horizontal (left) */
     int mode, sad4[4];
     int dx = iabs(p[0] - p[15]) + iabs(p[15*16] - p[15*16 + 15]) + iabs(p[8*16] - p[8*16 + 15]);
@@ -650,18 +672,19 @@ DEV void intra16_choose(RowLds &L, MbCtx &m)
     else if (dy > 30 + 3*dx && dx < (100 + 50 - m.qp) && (v & 2)) mode = 1;
     else mode = 2;
     m.i16_mode = mode;
-    wave_pred16(L.gtest[0], L.pix_left, L.pix_top, m.avail, mode);
-    int sad = wave_sad_lds_q(L.inp, L.gtest[0], sad4) + MUL_LAMBDA(ue_len((uint32_t)mode + 1), m.lambda_q4) + m.lambda_i16;
-    if (sad < m.cost)
-    {
-        m.cost = sad;
-        m.type = 6;
-        wave_copy_wh(L.pred, L.gtest[0], 16, 16);
-    }
+    wave_pred16(L.i16pred, L.pix_left, B.pix_top, m.avail, mode);
+    return wave_sad_lds_q(B.inp, L.i16pred, sad4) + MUL_LAMBDA(ue_len((uint32_t)mode + 1), m.lambda_q4) + m.lambda_i16;
 }
 
-/* H:4723-4833 intra_choose_4x4: 16 blocks in raster order, each predicted from reconstructed neighbours */
-DEV void intra4_choose(RowLds &L, MbCtx &m)
+#define I4_LOST 0x7fffffff
+/*
+ * H:4723-4833 intra_choose_4x4: 16 blocks in raster order, each predicted from reconstructed neighbours.  Returns the cost, or I4_LOST as
+ * soon as the cost -- which only grows -- reaches `bound()`: intra 4x4 wins only with a cost strictly below the best of the other
+ * decisions (H:4827), and nothing else of this function is observable for another macroblock type (mb_decide resets the mode contexts,
+ * mb_write computes luma again).  bound() is asked again after every block: in the two-wave pipeline the inter cost may arrive while
+ * this runs, and any upper bound of the final comparison value gives the same decision.  nz_mask_out: coded-block mask of a complete run.
+ */
+template <class BOUND> DEV int intra4_choose(RowLds &L, MbBuf &B, const MbCtx &m, BOUND bound, unsigned &nz_mask_out)
 {
     /* H:4750-4752 block2avail {07 23 23 2b 9b 77 ff 77 9b ff ff 77 9b 77 ff 77}: low nibble = mask on the macroblock's
      * flags, high nibble = flags forced on; one byte per block, packed so the lookup needs no memory */
@@ -670,11 +693,11 @@ DEV void intra4_choose(RowLds &L, MbCtx &m)
     const int avail = m.avail;
     int cost = m.lambda_i4;
     unsigned nz_mask = 0;
-    if (cost >= m.cost) return;
+    if (cost >= bound()) return I4_LOST;
     WAVE_FOR(l)
     {
-        if (l < 16) { r0[-24 + l] = L.pix_top[l]; r0[24*l - 1] = L.pix_left[l]; }
-        else if (l < 20) r0[-24 + l] = L.pix_top[32 + l - 16];
+        if (l < 16) { r0[-24 + l] = B.pix_top[l]; r0[24*l - 1] = L.pix_left[l]; }
+        else if (l < 20) r0[-24 + l] = B.pix_top[32 + l - 16];
         else if (l == 20) r0[-24 - 1] = L.pix_tl[0];
     }
     wave_sync();
@@ -682,18 +705,18 @@ DEV void intra4_choose(RowLds &L, MbCtx &m)
     {
         const int r = n >> 2, c = n & 3;
         uint8_t *blk = r0 + 24*4*r + 4*c;
-        const uint8_t *bin = L.inp + (c + r*16)*4;
+        const uint8_t *bin = B.inp + (c + r*16)*4;
         uint8_t *pr = L.tt;                                     /* prediction / reconstruction of this block, stride 16 */
         const int b2a = (int)(((n < 8 ? b2a_lo : b2a_hi) >> (8*(n & 7))) & 0xff);
         int a = (avail & b2a) | (b2a >> 4);
         if (!(b2a & AV_TL))
             if ((n <= 3 && (avail & AV_T)) || (n > 3 && (avail & AV_L))) a |= AV_TL;
         if (n < 3 && (avail & AV_T)) a |= AV_TR;
-        int mpred = imin(L.i4_left[r], L.i4_top[c]);
+        int mpred = imin(L.i4_left[r], B.i4_top[c]);
         if (mpred < 0) mpred = 2;
         int res = wave_i4_choose(bin, pr, a, blk - 24, blk - 1, 24, mpred, MUL_LAMBDA(3, m.lambda_q4), L.i4s);
         const int mode = res & 15, sad = res >> 4;
-        L.i4_left[r] = L.i4_top[c] = (int8_t)mode;
+        L.i4_left[r] = B.i4_top[c] = (int8_t)mode;
         L.i4_mode[n] = (int8_t)(mode == mpred ? -1 : mode > mpred ? mode - 1 : mode);
         unsigned coded = 0;
         if (sad > m.skip_thr_i4)
@@ -707,24 +730,76 @@ DEV void intra4_choose(RowLds &L, MbCtx &m)
         }
         nz_mask = (nz_mask << 1) | coded;
         cost += sad;
-        /* the cost only grows: once it reaches the best cost so far intra 4x4 cannot win (H:4827) and nothing else of this
-         * function is observable for another macroblock type -- mb_write resets the mode contexts and recomputes luma */
-        if (cost >= m.cost) return;
+        if (cost >= bound()) return I4_LOST;
         WAVE_FOR(l) { if (l < 4) lds32_store(blk + 24*l, lds32(pr + 16*l)); }
         wave_sync();
     }
-    m.nz_mask = nz_mask & 0xffff;
-    if (cost < m.cost)
+    nz_mask_out = nz_mask & 0xffff;
+    return cost;
+}
+
+/* H:5748-5762: the intra candidates against the inter decision, in the reference's order (16x16 first, then 4x4), strict "<" */
+DEV void intra_merge(RowLds &L, MbBuf &B, MbCtx &m, int cost16, int cost4, unsigned nz4)
+{
+    if (cost16 < m.cost)
     {
-        m.cost = cost;
-        m.type = 5;
+        m.cost = cost16;
+        m.type = 6;
+        wave_copy_wh(B.pred, L.i16pred, 16, 16);
     }
+    if (cost4 != I4_LOST && cost4 < m.cost)
+    {
+        m.cost = cost4;
+        m.type = 5;
+        m.nz_mask = nz4;
+    }
+}
+
+/* ------------------------------------------------------------------ decision -> contexts */
+
+/*
+ * The decision of the macroblock is final (m.type: -1 skip, 0..3 inter partitioning, 5 intra 4x4, 6 intra 16x16): bring the contexts
+ * that the NEXT macroblock's decisions read up to date -- the vector predictor context (H:3696-3715 me_mv_medianpredictor_put as
+ * mb_write calls it, H:4502, H:4560, H:4583: a skip and a 16x16 partition put the same vector, so the roll-back to skip inside mb_write
+ * changes nothing here) and the intra 4x4 mode contexts (H:4404-4410) -- after keeping the neighbours' vectors for this macroblock's
+ * deblocking strengths (H:5291-5296).  This is the hand-off point of the two-wave pipeline: the search of macroblock x + 1 starts here
+ * while x is still being transformed, coded and filtered.
+ */
+DEV void mb_decide(RowLds &L, MbBuf &B, const MbCtx &m)
+{
+    if (m.slice_type == 0)
+        for (int i = 0; i < 4; i++)
+        {
+            L.df_mv[4 + 5*i] = L.mv_left[i];
+            L.df_mv[i] = B.mv_top[i];
+        }
+    wave_sync();
+    if (m.type != 5)
+        for (int i = 0; i < 4; i++) L.i4_left[i] = B.i4_top[i] = 2;
+    if (m.type >= 5) mvp_put(L, B, 0, 0, 4, 4, MV_NA);
+    else if (m.type <= 0) mvp_put(L, B, 0, 0, 4, 4, B.mv[0]);
+    else
+    {
+        const int dx = (m.type & 2) ? 2 : 4, dyb = (m.type & 1) ? 2 : 4;
+        int x = 0, y = 0;
+        for (int part = 0;; part++)
+        {
+            mvp_put(L, B, x, y, dx, dyb, B.mv[part]);
+            x = (x + dx) & 3;
+            if (!x)
+            {
+                y = (y + dyb) & 3;
+                if (!y) break;
+            }
+        }
+    }
+    wave_sync();
 }
 
 /* ------------------------------------------------------------------ macroblock write */
 
 /* H:4378-4715 mb_write.  Reconstruction goes to the LDS deblock tiles; bits to the row buffer. */
-DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
+DEV void mb_write(RowLds &L, MbBuf &B, MbCtx &m, BitW &b)
 {
 #define SCAN8(i) ((((i) >> 3) & 1)*8 + (((i) >> 1) & 1)*4 + (((i) >> 2) & 1)*2 + ((i) & 1))     /* H:920 decode_block_scan */
     const int i16 = m.type >= 6;
@@ -733,32 +808,29 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
     uint8_t *ty = L.ytile + 4*YT_STRIDE + 4;
     uint8_t *tc[2] = { L.ctile[0] + 2*CT_STRIDE + 2, L.ctile[1] + 2*CT_STRIDE + 2 };
 
-    if (m.type != 5)
-        for (int i = 0; i < 4; i++) L.i4_left[i] = L.i4_top[i] = 2;
-
-    L.df_nzflag = ((L.df_nzflag >> 4) & 0x84210) | L.df_nz_top;
+    L.df_nzflag = ((L.df_nzflag >> 4) & 0x84210) | B.df_nz_top;
     for (int i = 0; i < 4; i++)
     {
-        nz[5 + i] = L.nnz_top[i];
+        nz[5 + i] = B.nnz_top[i];
         nz[3 - i] = L.nnz_left[i];
     }
     nz[4] = 0;
     wave_sync();
-    for (int i = 0; i < 4; i++) L.nnz_top[i] = L.nnz_left[i] = 0;
+    for (int i = 0; i < 4; i++) B.nnz_top[i] = L.nnz_left[i] = 0;
 
     if (m.type != -1)
     {
         PTIC();
         if (m.type != 5)
         {
-            unsigned mask = wave_xform_quant(L.inp, L.pred, i16 ? QMODE_I16 : QMODE_INTER, L.qy, L.dcy, L.qdat[0]);
+            unsigned mask = wave_xform_quant(B.inp, B.pred, i16 ? QMODE_I16 : QMODE_INTER, L.qy, L.dcy, L.qdat[0]);
             m.nz_mask = mask & 0xffff;
             if (i16)
             {
                 quant_luma_dc(L.qy, L.dcy, L.lev_dcy, L.qdat[0]);
                 mask = 0xFFFF;
             }
-            wave_recon(ty, YT_STRIDE, L.pred, L.qy, 4, mask << 16);
+            wave_recon(ty, YT_STRIDE, B.pred, L.qy, 4, mask << 16);
         } else
         {
             WAVE_FOR(l)
@@ -778,7 +850,7 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
         {
             qblk_t *q = c ? L.qv : L.qu;
             int16_t *dc = c ? L.dcv : L.dcu;
-            unsigned mask = wave_xform_quant(L.inp_c + 8*c, L.pred_c + 8*c, QMODE_CHROMA, q, dc, L.qdat[1]);
+            unsigned mask = wave_xform_quant(B.inp_c + 8*c, L.pred_c + 8*c, QMODE_CHROMA, q, dc, L.qdat[1]);
             if (mask) cbpc = 2;
             const int dc_flag = quant_chroma_dc(q, dc, c ? L.lev_dcv : L.lev_dcu, L.qdat[1]);
             cbpc |= dc_flag;
@@ -797,19 +869,18 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
         }
         cbpc = imin(cbpc, 2);
         /* roll back to skip (H:4493-4499) */
-        if (!(m.type | cbpl | cbpc) && L.mv[0] == m.mv_skip_pred) m.type = -1;
+        if (!(m.type | cbpl | cbpc) && B.mv[0] == m.mv_skip_pred) m.type = -1;
     }
 
     if (m.type == -1)
     {
         L.skip_run++;
-        for (int i = 4; i < 8; i++) L.nnz_top[i] = L.nnz_left[i] = 0;
-        mvp_put(L, 0, 0, 4, 4, L.mv[0]);
-        for (int i = 0; i < 16; i++) L.df_mv[5 + 5*(i >> 2) + (i & 3)] = L.mv[0];
+        for (int i = 4; i < 8; i++) B.nnz_top[i] = L.nnz_left[i] = 0;
+        for (int i = 0; i < 16; i++) L.df_mv[5 + 5*(i >> 2) + (i & 3)] = B.mv[0];
         WAVE_FOR(l)
         {
             int r = l >> 2, c = l & 3;
-            lds32_store(ty + YT_STRIDE*r + 4*c, lds32(L.pred + 16*r + 4*c));
+            lds32_store(ty + YT_STRIDE*r + 4*c, lds32(B.pred + 16*r + 4*c));
             if (l < 32)
             {
                 int pl = l >> 4, rr = (l >> 1) & 7, g = l & 1;
@@ -846,18 +917,16 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
             int cm = m.i16_mode;
             if (!(cm & 1)) cm ^= 2;
             bw_ue(b, (uint32_t)cm);
-            mvp_put(L, 0, 0, 4, 4, MV_NA);
         } else
         {
             const int dx = (m.type & 2) ? 2 : 4, dyb = (m.type & 1) ? 2 : 4;
             int x = 0, y = 0;
             for (int part = 0;; part++)
             {
-                bw_se(b, mvx(L.mvd[part]));
-                bw_se(b, mvy(L.mvd[part]));
-                mvp_put(L, x, y, dx, dyb, L.mv[part]);
+                bw_se(b, mvx(B.mvd[part]));
+                bw_se(b, mvy(B.mvd[part]));
                 for (int yy = 0; yy < dyb; yy++)
-                    for (int xx = 0; xx < dx; xx++) L.df_mv[5 + 5*(y + yy) + x + xx] = L.mv[part];
+                    for (int xx = 0; xx < dx; xx++) L.df_mv[5 + 5*(y + yy) + x + xx] = B.mv[part];
                 x = (x + dx) & 3;
                 if (!x)
                 {
@@ -884,7 +953,7 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
             }
             for (int i = 0; i < 4; i++)
             {
-                L.nnz_top[i] = nz[1 + i];
+                B.nnz_top[i] = nz[1 + i];
                 L.nnz_left[i] = nz[7 - i];
             }
         }
@@ -901,7 +970,7 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
                     nzc[2] = 0;
                     for (int i = 0; i < 2; i++)
                     {
-                        nzc[3 + i] = L.nnz_top[off + i];
+                        nzc[3 + i] = B.nnz_top[off + i];
                         nzc[1 - i] = L.nnz_left[off + i];
                     }
                     for (int i = 0; i < 4; i++)
@@ -911,13 +980,13 @@ DEV void mb_write(RowLds &L, MbCtx &m, BitW &b)
                     }
                     for (int i = 0; i < 2; i++)
                     {
-                        L.nnz_top[off + i] = nzc[1 + i];
+                        B.nnz_top[off + i] = nzc[1 + i];
                         L.nnz_left[off + i] = nzc[3 - i];
                     }
                 }
         }
         if (cbpc != 2)
-            for (int i = 4; i < 8; i++) L.nnz_top[i] = L.nnz_left[i] = 0;
+            for (int i = 4; i < 8; i++) B.nnz_top[i] = L.nnz_left[i] = 0;
     }
     wave_sync();
 #undef SCAN8

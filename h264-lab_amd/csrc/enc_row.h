@@ -58,7 +58,8 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
     L.bw.acc = 0; L.bw.nacc = 0; L.bw.pos = 0; L.bw.overflow = 0;
     L.bw.cap = (uint32_t)G.row_words;
     L.bw.buf = C.rowbits + (size_t)row*G.row_words;
-    L.skip_run = 0; L.lead_skips = 0; L.coded_any = 0; L.far_reads = 0; L.far_fail = 0;
+    L.skip_run = 0; L.lead_skips = 0; L.coded_any = 0; L.far_reads[0] = L.far_reads[1] = 0; L.far_fail[0] = L.far_fail[1] = 0;
+    L.f_loaded = L.f_noskip = L.f_inter = L.f_decided = L.f_wdone = L.f_stop = 0;
     WAVE_FOR(l) { if (l <= H264E_MAX_SLICES) L.slice_row[l] = l <= T.nslices ? T.slice_row[l] : (int16_t)0x7fff; }
     WAVE_FOR(l)
     {
@@ -69,19 +70,20 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
     df_tab_load(L.dftab);
     L.qconst[0] = k_lambda_mv_q4[T.qp]; L.qconst[1] = k_lambda_q4[T.qp]; L.qconst[2] = k_skip_thr_inter[T.qp];
     L.qconst[3] = k_skip_thr_i4x4[T.qp]; L.qconst[4] = k_lambda_i4_q4[T.qp]; L.qconst[5] = k_lambda_i16_q4[T.qp];
-    for (int i = 0; i < 32; i++) L.prof[i] = 0;
-    L.prof_last = 0;
+    for (int i = 0; i < 32; i++) L.prof[0][i] = L.prof[1][i] = 0;
+    L.prof_last[0] = L.prof_last[1] = 0;
 #if defined(H264E_STAMPS) && !defined(H264E_EMU)
     L.prof_c0 = __builtin_readcyclecounter(); L.prof_w0 = wall_clock64();      /* shader-clock cycles vs constant 100 MHz clock: effective frequency */
 #endif
     wave_sync();
-    STAMP(L, 31);
-    L.prof[31] = 0;
+#if defined(H264E_STAMPS) && !defined(H264E_EMU)
+    L.prof_last[0] = L.prof_last[1] = __builtin_readcyclecounter();
+#endif
 }
 
 /* neighbour record of the macroblock above -> LDS (h264-lab.h:742-745 contexts, :590-606 deblock state): 16 coherent dword
  * loads of the record (+2 of the record to its right), staged in LDS, then unpacked */
-DEV void load_top(RowLds &L, const h264e_geom_t &G, const GLOBAL_AS h264e_mbbottom_t *above, const GLOBAL_AS h264e_mbpend_t *pend_above, int x, int have_top)
+DEV void load_top(RowLds &L, MbBuf &B, const h264e_geom_t &G, const GLOBAL_AS h264e_mbbottom_t *above, const GLOBAL_AS h264e_mbpend_t *pend_above, int x, int have_top)
 {
     if (have_top)
     {
@@ -90,35 +92,35 @@ DEV void load_top(RowLds &L, const h264e_geom_t &G, const GLOBAL_AS h264e_mbbott
             if (l < 16) lds32_store(L.trec + 4*l, cload32((const gu8 *)(above + x) + 4*l));
             else if (l == 16) lds32_store(L.trec + 64, x + 1 < G.nmbx ? cload32((const gu8 *)(above + x + 1)) : 0u);                /* pix[0..3] of the above-right record */
             else if (l == 17) lds32_store(L.trec + 68, x + 1 < G.nmbx ? cload32((const gu8 *)(above + x + 1) + 32) : 0u);           /* its mv[0] */
-            else if (l >= 32 && l < 56) lds32_store(L.ptop + 4*(l - 32), cload32((const gu8 *)(pend_above + x) + 4*(l - 32)));    /* for the deblocking at the end of the step */
+            else if (l >= 32 && l < 56) lds32_store(B.ptop + 4*(l - 32), cload32((const gu8 *)(pend_above + x) + 4*(l - 32)));    /* for the deblocking at the end of the step */
         }
         wave_sync();
         WAVE_FOR(l)
         {
-            if (l < 8) lds32_store(L.pix_top + 4*l, lds32(L.trec + 4*l));
-            else if (l < 12) L.mv_top[l - 8] = (mv32)lds32(L.trec + 32 + 4*(l - 8));
-            else if (l < 20) L.nnz_top[l - 12] = L.trec[48 + l - 12];
-            else if (l < 24) L.i4_top[l - 20] = (int8_t)L.trec[56 + l - 20];
-            else if (l == 24) { L.df_nz_top = L.trec[60]; L.top_type = (int8_t)L.trec[61]; L.top_qp = L.trec[62]; }
-            else if (l == 25) lds32_store(L.pix_top + 32, lds32(L.trec + 64));
-            else if (l == 26) L.mv_top[4] = (mv32)lds32(L.trec + 68);
+            if (l < 8) lds32_store(B.pix_top + 4*l, lds32(L.trec + 4*l));
+            else if (l < 12) B.mv_top[l - 8] = (mv32)lds32(L.trec + 32 + 4*(l - 8));
+            else if (l < 20) B.nnz_top[l - 12] = L.trec[48 + l - 12];
+            else if (l < 24) B.i4_top[l - 20] = (int8_t)L.trec[56 + l - 20];
+            else if (l == 24) { B.df_nz_top = L.trec[60]; B.top_type = (int8_t)L.trec[61]; B.top_qp = L.trec[62]; }
+            else if (l == 25) lds32_store(B.pix_top + 32, lds32(L.trec + 64));
+            else if (l == 26) B.mv_top[4] = (mv32)lds32(L.trec + 68);
         }
     } else
     {
         WAVE_FOR(l)
         {
-            if (l < 36) L.pix_top[l] = 0;
-            if (l < 5) L.mv_top[l] = 0;
-            if (l < 8) L.nnz_top[l] = NNZ_NA;
-            if (l < 4) L.i4_top[l] = -1;
-            if (l == 0) { L.df_nz_top = 0; L.top_type = 0; L.top_qp = 0; }
+            if (l < 36) B.pix_top[l] = 0;
+            if (l < 5) B.mv_top[l] = 0;
+            if (l < 8) B.nnz_top[l] = NNZ_NA;
+            if (l < 4) B.i4_top[l] = -1;
+            if (l == 0) { B.df_nz_top = 0; B.top_type = 0; B.top_qp = 0; }
         }
     }
     wave_sync();
 }
 
 /* h264-lab.h:5731-5740 + 3536-3562: input macroblock -> LDS, replicating the last valid column / row of cropped pictures */
-DEV void load_input(RowLds &L, const h264e_geom_t &G, const RowTask &T, int mbx, int mby)
+DEV void load_input(MbBuf &B, const h264e_geom_t &G, const RowTask &T, int mbx, int mby)
 {
     WAVE_FOR(l)
     {
@@ -127,15 +129,16 @@ DEV void load_input(RowLds &L, const h264e_geom_t &G, const RowTask &T, int mbx,
             const gu8 *p = (const gu8 *)T.in[0] + (size_t)yy*T.in_stride[0];
             uint32_t v = 0;
             for (int k = 0; k < 4; k++) v |= (uint32_t)p[imin(mbx*16 + 4*c + k, G.width - 1)] << (8*k);
-            lds32_store(L.inp + 16*r + 4*c, v);
+            lds32_store(B.inp + 16*r + 4*c, v);
         }
         if (l < 32)
         {
             int pl = l >> 4, r = (l >> 1) & 7, c = l & 1, yy = imin(mby*8 + r, G.height/2 - 1);
-            const gu8 *p = (const gu8 *)T.in[1 + pl] + (size_t)yy*T.in_stride[1 + pl];
+            /* (selected, not indexed: a lane-varying index would put the task copy into scratch memory) */
+            const gu8 *p = (const gu8 *)(pl ? T.in[2] : T.in[1]) + (size_t)yy*(pl ? T.in_stride[2] : T.in_stride[1]);
             uint32_t v = 0;
             for (int k = 0; k < 4; k++) v |= (uint32_t)p[imin(mbx*8 + 4*c + k, G.width/2 - 1)] << (8*k);
-            lds32_store(L.inp_c + 16*r + 8*pl + 4*c, v);
+            lds32_store(B.inp_c + 16*r + 8*pl + 4*c, v);
         }
     }
     wave_sync();
@@ -146,7 +149,7 @@ DEV void load_input(RowLds &L, const h264e_geom_t &G, const RowTask &T, int mbx,
  * the HBM latency of these loads overlaps with that wait. */
 DEV void row_prefetch(RowLds &L, const h264e_geom_t &G, const RowTask &T, int row, int x)
 {
-    load_input(L, G, T, x, row);
+    load_input(L.mb[x & 1], G, T, x, row);
     if (T.slice_type == 0)
     {
         Plane P;
@@ -155,15 +158,23 @@ DEV void row_prefetch(RowLds &L, const h264e_geom_t &G, const RowTask &T, int ro
     }
 }
 
-/* NARROW: compile-time choice of the reference-window geometry (h264e_dev.h) */
-/* row0 / row1: first row and end row of the slice (row band) this row belongs to -- the whole picture for one slice per frame.
+/*
+ * One macroblock = three phases (the reference's mb_encode, h264-lab.h:5724-5812, cut where its data flow allows two instruction streams):
+ *   mb_search        neighbour records of the row above -> LDS, inter decision (H:5283-5524)                     [search side]
+ *   mb_intra_decide  intra 16x16 / 4x4 candidates (H:5748-5762), the final decision, contexts for the next one   [reconstruction side]
+ *   mb_recon_write   chroma prediction, mb_write (H:4378-4715), deblocking (H:5535-5716), stores                 [reconstruction side]
+ * The search of macroblock x + 1 needs nothing of x but the predictor context that mb_intra_decide leaves behind, and the intra
+ * candidates of x + 1 need the reconstruction of x (left column) -- so with two wavefronts per row (h264e_kernels.hip) the search
+ * wave works on x + 1 while the reconstruction wave writes x, then tests the intra candidates of x + 1.  With one wavefront (and in
+ * the emulation) the three run one after the other; the decisions are the same either way.
+ * NARROW: compile-time choice of the reference-window geometry (h264e_dev.h).
+ * row0 / row1: first row and end row of the slice (row band) this row belongs to -- the whole picture for one slice per frame.
  * A slice is encoded like a picture of its own as far as neighbour availability, contexts and deblocking are concerned
- * (h264-lab.h:3605-3622 mb_avail_flag relative to slice.start_mb_num, h264-lab.h:5799-5808 no filtering across its top edge). */
-template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const RowTask &T, int row, int x, int row0, int row1)
+ * (h264-lab.h:3605-3622 mb_avail_flag relative to slice.start_mb_num, h264-lab.h:5799-5808 no filtering across its top edge).
+ */
+template <bool NARROW> DEV void mb_ctx_init(MbCtx &m, RowLds &L, const h264e_geom_t &G, const RowTask &T, int row, int x, int row0, int side)
 {
     const bool have_top = row > row0;
-    MbCtx m;
-    PTIC();
     m.G = &G;
     m.speed = T.speed; m.slice_type = T.slice_type; m.clu[0] = T.clusters[0]; m.clu[1] = T.clusters[1]; m.clu_per_mb = T.clusters_per_mb;
     for (int c = 0; c < 3; c++)
@@ -180,39 +191,86 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
     m.qp = T.qp;
     m.lambda_mv = uni(L.qconst[0]); m.lambda_q4 = uni(L.qconst[1]); m.skip_thr = uni(L.qconst[2]);
     m.skip_thr_i4 = uni(L.qconst[3]); m.lambda_i4 = uni(L.qconst[4]); m.lambda_i16 = uni(L.qconst[5]);
-
-    GLOBAL_AS h264e_mbbottom_t *rowrec = C.bottom + (size_t)row*G.nmbx;
-    STAMP(L, 0);
-    load_top(L, G, rowrec - G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, have_top);
-    /* the input macroblock and the reference window are already in LDS (row_prefetch) */
     m.rv.dep = (const GLOBAL_AS int *)T.dep_progress; m.rv.nmbx = G.nmbx; m.rv.nmby = G.nmby;
     m.rv.P = m.ref[0]; m.rv.win = (const lu8 *)L.win; m.rv.has_win = T.slice_type == 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
-    m.rv.vw = NARROW ? H264E_NARROW_VW : WIN_W; m.rv.vh = NARROW ? H264E_NARROW_VH : WIN_W; m.rv.far = &L.far_reads; m.rv.fail = &L.far_fail; m.rv.slice_row = L.slice_row; m.rv.nslices = T.nslices; m.rv.spin_limit = G.spin_limit;
+    m.rv.vw = NARROW ? H264E_NARROW_VW : WIN_W; m.rv.vh = NARROW ? H264E_NARROW_VH : WIN_W; m.rv.far = &L.far_reads[side]; m.rv.fail = &L.far_fail[side]; m.rv.slice_row = L.slice_row; m.rv.nslices = T.nslices; m.rv.spin_limit = G.spin_limit;
+}
+
+/* search side.  The input macroblock, the reference window (row_prefetch) and the records of the row above (load_top) are already in
+ * LDS.  noskip() is called once the
+ * early-skip test has failed (the reconstruction side may start on the intra candidates then). */
+template <bool NARROW, class HOOK> DEV void mb_search(RowLds &L, MbBuf &B, const h264e_geom_t &G, const RowTask &T, int row, int x, int row0, HOOK noskip)
+{
+    MbCtx m;
+    mb_ctx_init<NARROW>(m, L, G, T, row, x, row0, 0);
     STAMP(L, 1);
-
-    BitW bw = L.bw;
-
-    if (T.slice_type == 0) inter_choose(L, m);
+    if (T.slice_type == 0) inter_choose(L, B, m, noskip);
     STAMP(L, 7);
+    B.type = m.type; B.cost = m.cost; B.used_cand = m.used_cand; B.mv_skip_pred = m.mv_skip_pred;
+    wave_sync();
+}
+
+/* How the reconstruction side learns about the inter decision: it is simply there (one wavefront, emulation) ... */
+struct InterIsThere
+{
+    DEVM bool ready() const { return true; }
+    DEVM bool wait_noskip_or_ready() const { return true; }
+    DEVM bool wait_ready() const { return true; }
+};
+
+/* reconstruction side, first half: the intra candidates and the final decision.  The intra candidates do not need the inter decision
+ * -- only the comparison at the end does -- so with a search wave still at work (P.ready() false) they start as soon as the early-skip
+ * test has failed, bounded by the 16x16 intra cost until the inter cost arrives.  Returns false when the row has to stop. */
+template <class P> DEV bool mb_intra_decide(RowLds &L, MbBuf &B, MbCtx &m, const RowTask &T, P pol)
+{
+    bool have = pol.ready();
+    if (!have)
+    {
+        if (!pol.wait_noskip_or_ready()) return false;
+        have = pol.ready();
+    }
+    STAMP(L, 15);               /* two waves: waited for the search wave's early-skip test */
+    if (have) { m.type = uni(B.type); m.cost = uni(B.cost); }
     if (m.type >= 0)
     {
-        intra16_choose(L, m);
+        const int cost16 = intra16_cost(L, B, m);
         STAMP(L, 8);
-        if (T.speed < 2 || T.slice_type != 0) intra4_choose(L, m);
+        int cost4 = I4_LOST, bnd = imin(m.cost, cost16);
+        unsigned nz4 = 0;
+        if (T.speed < 2 || T.slice_type != 0)
+            cost4 = intra4_choose(L, B, m, [&]() -> int {
+                if (!have && pol.ready()) { have = true; bnd = imin(bnd, uni(B.cost)); }
+                return bnd;
+            }, nz4);
         STAMP(L, 9);
+        if (!pol.wait_ready()) return false;
+        STAMP(L, 16);           /* two waves: waited for the inter decision */
+        m.type = uni(B.type); m.cost = uni(B.cost);
+        if (m.type >= 0) intra_merge(L, B, m, cost16, cost4, nz4);
     }
-    if (m.type >= 5) wave_pred_chroma(L.pred_c, L.pix_left + 16, L.pix_top + 16, m.avail, m.i16_mode);
-    else predict_chroma_inter(L, m);
+    m.used_cand = uni(B.used_cand); m.mv_skip_pred = (mv32)uni(B.mv_skip_pred);
+    mb_decide(L, B, m);
+    return true;
+}
+
+/* reconstruction side, second half */
+template <bool NARROW> DEV void mb_recon_write(RowLds &L, MbBuf &B, MbCtx &m, const h264e_geom_t &G, const ChainG &C, const RowTask &T, int row, int x, int row0, int row1)
+{
+    const bool have_top = row > row0;
+    GLOBAL_AS h264e_mbbottom_t *rowrec = C.bottom + (size_t)row*G.nmbx;
+    if (m.type >= 5) wave_pred_chroma(L.pred_c, L.pix_left + 16, B.pix_top + 16, m.avail, m.i16_mode);
+    else predict_chroma_inter(B, m, L.pred_c);
 
     STAMP(L, 10);
-    mb_write(L, m, bw);
+    BitW bw = L.bw;
+    mb_write(L, B, m, bw);
     L.bw = bw;
     STAMP(L, 11);
 
     /* record for the mv_clusters validation (h264-lab.h:5776-5779 updates them with mv[0] of every non-intra MB) */
     {
         GLOBAL_AS h264e_mbrec_t *rec = C.mbrec + (size_t)T.frame_slot*G.nmb + m.num;
-        const uint32_t mv0 = m.type < 5 ? (uint32_t)L.mv[0] : 0u;
+        const uint32_t mv0 = m.type < 5 ? (uint32_t)B.mv[0] : 0u;
         const uint64_t w = (uint64_t)mv0 | ((uint64_t)(uint8_t)(int8_t)m.type << 32) | ((uint64_t)(m.used_cand & 255) << 40);
         if (wave_lane() == 0) cstore64((gu8 *)rec, w);
     }
@@ -236,7 +294,7 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
         } else if (l < 35)
         {
             int c = l - 32;
-            L.pix_tl[c] = L.pix_top[c == 0 ? 15 : 15 + 8*c];
+            L.pix_tl[c] = B.pix_top[c == 0 ? 15 : 15 + 8*c];
         }
     }
     wave_sync();
@@ -250,7 +308,7 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
     const bool direct = T.no_deblock || row == row1 - 1;        /* nothing below will filter the bottom lines (picture or slice end): they are final now */
     if (!T.no_deblock)
     {
-        df_strength(L, m, L.top_type);
+        df_strength(L, m, B.top_type);
         WAVE_FOR(l)
         {
             if (l < 16) lds32_store(L.ytile + (4 + l)*YT_STRIDE, lds32(L.strip_y + 4*l));
@@ -263,18 +321,18 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
             {
                 int r = (l - 32) >> 2, c = l & 3;
                 uint32_t v = 0;
-                if (have_top) v = lds32(L.ptop + 16*r + 4*c);
+                if (have_top) v = lds32(B.ptop + 16*r + 4*c);
                 lds32_store(L.ytile + r*YT_STRIDE + 4 + 4*c, v);
             } else if (l < 56)
             {
                 int pl = (l >> 2) & 1, r = (l >> 1) & 1, c = l & 1;
                 uint32_t v = 0;
-                if (have_top) v = lds32(L.ptop + 64 + 16*pl + 8*r + 4*c);
+                if (have_top) v = lds32(B.ptop + 64 + 16*pl + 8*r + 4*c);
                 memcpy(L.ctile[pl] + r*CT_STRIDE + 2 + 4*c, &v, 4);
             }
         }
         wave_sync();
-        wave_deblock(L.ytile, L.ctile[0], L.ctile[1], L.bs, T.qp, L.left_qp, L.top_qp, L.dftab);
+        wave_deblock(L.ytile, L.ctile[0], L.ctile[1], L.bs, T.qp, L.left_qp, B.top_qp, L.dftab);
     }
     /* write the macroblock: final lines into the picture, the bottom lines into the pending record; 8 bytes per lane (every
      * store is one write-through fabric request, whatever its width) */
@@ -351,9 +409,9 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
             int pl = (l >> 3) & 1, i = l & 7;
             const uint8_t *t = (pl ? tc1 : tc0) + CT_STRIDE*i + 4;
             L.strip_c[pl][4*i] = t[0]; L.strip_c[pl][4*i + 1] = t[1]; L.strip_c[pl][4*i + 2] = t[2]; L.strip_c[pl][4*i + 3] = t[3];
-        } else if (l < 36) lds32_store(L.brec + 32 + 4*(l - 32), (uint32_t)L.mv_top[l - 32]);
-        else if (l < 44) L.brec[48 + l - 36] = L.nnz_top[l - 36];
-        else if (l < 48) L.brec[56 + l - 44] = (uint8_t)L.i4_top[l - 44];
+        } else if (l < 36) lds32_store(L.brec + 32 + 4*(l - 32), (uint32_t)B.mv_top[l - 32]);
+        else if (l < 44) L.brec[48 + l - 36] = B.nnz_top[l - 36];
+        else if (l < 48) L.brec[56 + l - 44] = (uint8_t)B.i4_top[l - 44];
         else if (l == 48)
         {
             L.brec[60] = (uint8_t)(L.df_nzflag >> 20);
@@ -369,7 +427,18 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
     wave_sync();
     STAMP(L, 12);
     PCOUNT(L, 20 + (m.type < 0 ? 0 : m.type < 5 ? 1 : 2));
-    PTOC(L, 24 + (m.type < 0 ? 0 : m.type < 5 ? 1 : 2));
+}
+
+/* the three phases one after the other: one wavefront per row, and the emulation */
+template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const RowTask &T, int row, int x, int row0, int row1)
+{
+    MbBuf &B = L.mb[x & 1];
+    MbCtx m;
+    load_top(L, B, G, C.bottom + (size_t)(row - 1)*G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, row > row0);
+    mb_search<NARROW>(L, B, G, T, row, x, row0, []() {});
+    mb_ctx_init<NARROW>(m, L, G, T, row, x, row0, 1);
+    mb_intra_decide(L, B, m, T, InterIsThere());
+    mb_recon_write<NARROW>(L, B, m, G, C, T, row, x, row0, row1);
 }
 
 DEV void row_end(RowLds &L, const h264e_geom_t &G, const ChainG &C, int row)
@@ -385,9 +454,9 @@ DEV void row_end(RowLds &L, const h264e_geom_t &G, const ChainG &C, int row)
     if (wave_lane() == 0)
     {
 #ifdef H264E_EMU
-        *C.far_reads += L.far_reads;
+        *C.far_reads += L.far_reads[0] + L.far_reads[1];
 #else
-        if (L.far_reads) __hip_atomic_fetch_add(C.far_reads, L.far_reads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (L.far_reads[0] + L.far_reads[1]) __hip_atomic_fetch_add(C.far_reads, L.far_reads[0] + L.far_reads[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
         cstore32(M, nbits);
         cstore32(M + 4, (uint32_t)(L.coded_any ? L.lead_skips : G.nmbx));
@@ -396,9 +465,9 @@ DEV void row_end(RowLds &L, const h264e_geom_t &G, const ChainG &C, int row)
     }
     wave_sync();
 #if defined(H264E_STAMPS) && !defined(H264E_EMU)
-    L.prof[28] = __builtin_readcyclecounter() - L.prof_c0; L.prof[29] = wall_clock64() - L.prof_w0;
+    L.prof[PROF_W][28] = __builtin_readcyclecounter() - L.prof_c0; L.prof[PROF_W][29] = wall_clock64() - L.prof_w0;
     wave_sync();
-    if (threadIdx.x < 32 && C.prof) atomicAdd(C.prof + threadIdx.x, L.prof[threadIdx.x]);
+    if (LANE < 32 && C.prof) atomicAdd(C.prof + LANE, L.prof[PROF_W][LANE]);
 #endif
 }
 

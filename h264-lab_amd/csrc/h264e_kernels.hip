@@ -48,8 +48,44 @@ DEV int poll_progress(const GLOBAL_AS int *flag, int need, int &seen, unsigned s
     }
 }
 
+/* ---- hand-off words of the two-wave pipeline (LDS): release / acquire at workgroup scope, polled with s_sleep */
+DEV int flag_get(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV void flag_set(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define LDS_SPIN_LIMIT (1u << 26)       /* the partner wave is resident: this bound only ever ends a wait when something is badly wrong */
+/* 0 = *flag reached need; otherwise the stop code the partner wave (or this bound) left: -1 failure, -2 abort */
+DEV int lds_wait(const int *flag, int need, int *stop)
+{
+    for (unsigned spins = 0;; spins++)
+    {
+        if (uni(flag_get(flag)) >= need) return 0;
+        const int s = uni(flag_get(stop));
+        if (s) return s;
+        if (spins > LDS_SPIN_LIMIT) { flag_set(stop, -1); return -1; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+/* the reconstruction wave's view of the inter decision of macroblock need - 1 (enc_row.h mb_intra_decide) */
+struct InterFromSearchWave
+{
+    RowLds *L;
+    int need;
+    DEVM bool ready() const { return uni(flag_get(&L->f_inter)) >= need; }
+    DEVM bool wait_ready() const { return lds_wait(&L->f_inter, need, &L->f_stop) == 0; }
+    DEVM bool wait_noskip_or_ready() const
+    {
+        for (unsigned spins = 0;; spins++)
+        {
+            if (uni(flag_get(&L->f_inter)) >= need || uni(flag_get(&L->f_noskip)) >= need) return true;
+            if (uni(flag_get(&L->f_stop))) return false;
+            if (spins > LDS_SPIN_LIMIT) { flag_set(&L->f_stop, -1); return false; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+};
+
 /*
- * Grid: njobs x (nmby + 1) workgroups of one wavefront.  Workgroup `row < nmby` encodes macroblock row
+ * Grid: njobs x (nmby + 1) workgroups of one wavefront -- or of two (WAVES = 2): the macroblock loop as a two-stage pipeline, one
+ * wavefront searching macroblock x + 1 while the other reconstructs and writes x (enc_row.h).  Workgroup `row < nmby` encodes macroblock row
  * `row` of its job's frame; workgroup `nmby` is the job's finalizer: once every row has ended it splices the slice
  * (finalize_frame) and, in streaming use, exports the result to host-mapped memory and raises the job's done word,
  * so the host consumes frames while later frames of the same launch are still being encoded.
@@ -58,16 +94,26 @@ DEV int poll_progress(const GLOBAL_AS int *flag, int need, int &seen, unsigned s
  * (a long vector) waits dynamically for the exact rows it touches, which can lie a bounded distance AHEAD in the dispatch
  * order (enc_kernels.h rv_wait_rect).  All spins are bounded; an expired one poisons the row counter and sets errflag.
  */
-template <bool NARROW>
-__global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h264e_chain_dev_t *chains,
-                                                         const h264e_frame_task_t *tasks, const uint32_t *order, int *errflag, int *stepflags)
+/* wavefronts per SIMD the register allocation aims at.  Measured (gpurun_out/r3_wpe3): the two-wave pipeline at 3 (168 VGPRs, a few
+ * spills, 6 rows per CU) beats 2 everywhere -- 1080p single slice 8.2 -> 8.9 M MB/s, 4K 10.8 -> 12.9 M; the one-wave kernel is
+ * better off at 2 (256 VGPRs): at 3 it spills 131 registers. */
+#ifndef H264E_WPE2
+#define H264E_WPE2 3
+#endif
+#ifndef H264E_WPE1
+#define H264E_WPE1 2
+#endif
+template <bool NARROW, int WAVES>
+__global__ void __launch_bounds__(64*WAVES, WAVES == 2 ? H264E_WPE2 : H264E_WPE1) h264e_mb_kernel(h264e_geom_t G, const h264e_chain_dev_t *chains,
+                                                               const h264e_frame_task_t *tasks, const uint32_t *order, int *errflag, int *stepflags)
 {
     __shared__ RowLds L;
+    const int wv = WAVES == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;     /* which wavefront of the workgroup */
 #ifdef H264E_LDS_PAD
     /* diagnostic build (Makefile `halfres`): extra LDS per workgroup so that fewer workgroups fit a CU -- what single-stream throughput
      * does when the resident rows are halved with the macroblock latency unchanged (the price of a multi-wave workgroup) */
     __shared__ volatile char lds_pad[H264E_LDS_PAD];
-    if (G.nmbx < 0) lds_pad[threadIdx.x] = 1;
+    if (G.nmbx < 0) lds_pad[LANE] = 1;
 #endif
     /* workgroups are dispatched in index order: `order` lists (job, row) by the step at which the row can start
      * (H264E_FRAME_LAG*job + 2*row), so the resident workgroups are the ones that can make progress */
@@ -79,14 +125,15 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
 
     if (row == G.nmby)
     {
-        /* ---- finalizer */
+        /* ---- finalizer (one wavefront; the second one of a two-wave workgroup has nothing to do here) */
+        if (wv) return;
         int st = 0, seen = 0;
         GLOBAL_AS h264e_hostdone_t *hd = (GLOBAL_AS h264e_hostdone_t *)T.host_done;
         GLOBAL_AS h264e_walkrec_t *wout = (GLOBAL_AS h264e_walkrec_t *)T.walk_out;
         for (int r = G.nmby - 1; r >= 0 && !st; r--) st = poll_progress(C.progress + r, G.nmbx + 1, seen, G.spin_limit);
         if (st)
         {
-            if (threadIdx.x == 0)
+            if (LANE == 0)
             {
                 if (st == -1) *errflag = 1;
                 if (T.walk_on_device && wout)
@@ -103,7 +150,7 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         int wstatus = 0, first_bad = -1;
         mv32 ws[2] = { T.exact_state[0], T.exact_state[1] };
         if (T.walk_on_device)
@@ -119,7 +166,7 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
                 {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
+                    __builtin_amdgcn_wave_barrier();
                     if (uni(wp->status) != H264E_WALK_OK) wstatus = H264E_WALK_VOID;
                     else { ws[0] = (mv32)uni(wp->state_out[0]); ws[1] = (mv32)uni(wp->state_out[1]); }
                 }
@@ -130,8 +177,8 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
                 wstatus = first_bad >= 0 ? H264E_WALK_BAD : H264E_WALK_OK;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0 && wout)
+            __builtin_amdgcn_wave_barrier();
+            if (LANE == 0 && wout)
             {
                 wout->state_out[0] = ws[0]; wout->state_out[1] = ws[1]; wout->status = wstatus; wout->first_bad = first_bad;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -140,7 +187,7 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
             }
             if (wstatus != H264E_WALK_OK)
             {
-                if (threadIdx.x == 0)
+                if (LANE == 0)
                 {
                     if (wstatus == H264E_WALK_BAD && T.abort_word && !T.walk_quiet)
                         __hip_atomic_store((GLOBAL_AS int *)T.abort_word, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -160,13 +207,13 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
         {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             uint32_t nal_bytes[H264E_MAX_SLICES], nal_total = 0;
             int exp_overflow = 0, in_device = 0;
             export_frame(G, C, T, nal_bytes, nal_total, exp_overflow, in_device);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0)
+            __builtin_amdgcn_wave_barrier();
+            if (LANE == 0)
             {
                 const GLOBAL_AS h264e_frameout_t &F = C.fout[T.frame_slot];
                 hd->nbytes = nal_total; hd->all_skipped = F.all_skipped;
@@ -186,96 +233,158 @@ __global__ void __launch_bounds__(64, 2) h264e_mb_kernel(h264e_geom_t G, const h
     /* ---- macroblock row */
     if (row < T.first_row) return;          /* kept from the previous encode of this frame (its counter already says complete) */
     if (job == 0 && row == G.test_stall_row) return;    /* fault injection: a producer that never publishes (tests/test_gpu_failures.py) */
-    row_begin(L, G, C, T, row);
+    if (wv == 0) row_begin(L, G, C, T, row);
+    if (WAVES == 2) __syncthreads();         /* the one workgroup barrier: both wavefronts see the row's tables and initial state */
     const RowTask RT = rowtask_load(T);      /* the task's hot fields, once, in registers */
-    const GLOBAL_AS int *abort_word = (const GLOBAL_AS int *)uniptr(T.abort_word);
-    const int launch_id = uni(T.launch_id);
-    int seen = 0, seen_dep = 0;
     int row0 = 0, row1 = G.nmby;            /* the slice (row band) this row belongs to */
     for (int k = 0; k < T.nslices; k++)
         if (row >= T.slice_row[k] && row < T.slice_row[k + 1]) { row0 = T.slice_row[k]; row1 = T.slice_row[k + 1]; }
     row0 = uni(row0); row1 = uni(row1);
-    constexpr int DEP_ROWS = NARROW ? H264E_NARROW_DEP_ROWS : H264E_DEP_ROWS, DEP_COLS = NARROW ? H264E_NARROW_DEP_COLS : H264E_DEP_COLS;
-    /* temporal wavefront: the reference window covers macroblock rows row-2 .. row+DEP_ROWS of the frame being referenced.
-     * Inside one slice the lowest of them is the last to get there; with row-band slices the bands advance independently, so
-     * every band the window touches is waited for at its lowest row inside the window (10 bits per row, lowest row first) */
-    unsigned long long deps = 0;
-    int ndeps = 0;
-    if (T.dep_progress)
+    GLOBAL_AS int *my_progress = C.progress + row;
+
+    if (WAVES == 1 || wv == 0)
     {
-        const int lo = imax(row - 2, 0), hi = imin(row + DEP_ROWS, G.nmby - 1);
-        deps = (unsigned long long)hi; ndeps = 1;
-        for (int k = T.nslices - 1; k >= 1; k--)
+        /* ---- the wave that waits for the neighbours and searches (with one wave per row: does everything) */
+        const GLOBAL_AS int *abort_word = (const GLOBAL_AS int *)uniptr(T.abort_word);
+        const int launch_id = uni(T.launch_id);
+        int seen = 0, seen_dep = 0;
+        constexpr int DEP_ROWS = NARROW ? H264E_NARROW_DEP_ROWS : H264E_DEP_ROWS, DEP_COLS = NARROW ? H264E_NARROW_DEP_COLS : H264E_DEP_COLS;
+        /* temporal wavefront: the reference window covers macroblock rows row-2 .. row+DEP_ROWS of the frame being referenced.
+         * Inside one slice the lowest of them is the last to get there; with row-band slices the bands advance independently, so
+         * every band the window touches is waited for at its lowest row inside the window (10 bits per row, lowest row first) */
+        unsigned long long deps = 0;
+        int ndeps = 0;
+        if (T.dep_progress)
         {
-            const int last = T.slice_row[k] - 1;            /* last row of slice k-1 */
-            if (last >= lo && last < hi) { deps |= (unsigned long long)last << (10*ndeps); ndeps++; }
-        }
-        ndeps = uni(ndeps);
-    }
-    for (int x = 0; x < G.nmbx; x++)
-    {
-        /* consumer: relaxed sc1 polls, then sc1 loads of everything handed over */
-        const int need = row > row0 ? imin(x + 2, G.nmbx) : 0;
-        const int need_dep = RT.dep_progress ? imin(x + DEP_COLS, G.nmbx) : 0;     /* temporal wavefront: h264e_dev.h */
-        int st = 0;
-        /* the abort word lives in device memory (raised by a finalizer whose mv_clusters walk failed, or by the host): one L2 read per macroblock */
-        if (abort_word && uni(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == launch_id) st = -2;
-        /* temporal dependency first, then the loads that only need it (input, reference window) ... */
-        if (!st && seen_dep < need_dep)
-        {
-            int lowest = 0x7fffffff;
-            for (int k = 0; k < ndeps && !st; k++)
+            const int lo = imax(row - 2, 0), hi = imin(row + DEP_ROWS, G.nmby - 1);
+            deps = (unsigned long long)hi; ndeps = 1;
+            for (int k = T.nslices - 1; k >= 1; k--)
             {
-                int sk = 0;
-                st = poll_progress((const GLOBAL_AS int *)RT.dep_progress + (int)((deps >> (10*k)) & 1023), need_dep, sk, G.spin_limit);
-                lowest = imin(lowest, sk);
+                const int last = T.slice_row[k] - 1;            /* last row of slice k-1 */
+                if (last >= lo && last < hi) { deps |= (unsigned long long)last << (10*ndeps); ndeps++; }
             }
-            seen_dep = lowest;
-            if (!st) consumer_acquire();
+            ndeps = uni(ndeps);
         }
-        if (!st) row_prefetch(L, G, RT, row, x);
-        /* ... so that their latency overlaps with the wait for the row above */
-        if (!st && seen < need)
+        for (int x = 0; x < G.nmbx; x++)
         {
-            st = poll_progress(C.progress + (row - 1), need, seen, G.spin_limit);
-            if (!st) consumer_acquire();
-        }
-        if (st)
-        {
-            /* stop: leave poison in this row's counter so everything behind it stops too (-1 failure, -2 abort) */
-            if (threadIdx.x == 0)
+            /* consumer: relaxed sc1 polls, then sc1 loads of everything handed over */
+            const int need = row > row0 ? imin(x + 2, G.nmbx) : 0;
+            const int need_dep = RT.dep_progress ? imin(x + DEP_COLS, G.nmbx) : 0;     /* temporal wavefront: h264e_dev.h */
+            int st = 0;
+            /* the abort word lives in device memory (raised by a finalizer whose mv_clusters walk failed, or by the host): one L2 read per macroblock */
+            if (abort_word && uni(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == launch_id) st = -2;
+            /* temporal dependency first, then the loads that only need it (input, reference window) ... */
+            if (!st && seen_dep < need_dep)
             {
-                if (st == -1) *errflag = 1;
-                __hip_atomic_store(C.progress + row, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
-        }
-        STAMP(L, 13);
-        row_step<NARROW>(L, G, C, RT, row, x, row0, row1);
-        {
-            /* a far reference read of this macroblock waited in vain (rv_wait_rect): what it encoded is not trustworthy */
-            const int ff = uni(L.far_fail);
-            if (ff)
-            {
-                if (threadIdx.x == 0)
+                int lowest = 0x7fffffff;
+                for (int k = 0; k < ndeps && !st; k++)
                 {
-                    if (ff == -1) *errflag = 1;
-                    __hip_atomic_store(C.progress + row, ff < -2 ? -2 : ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int sk = 0;
+                    st = poll_progress((const GLOBAL_AS int *)RT.dep_progress + (int)((deps >> (10*k)) & 1023), need_dep, sk, G.spin_limit);
+                    lowest = imin(lowest, sk);
+                }
+                seen_dep = lowest;
+                if (!st) consumer_acquire();
+            }
+            /* two waves: macroblock x uses the hand-off buffer of x - 2, which the reconstruction wave must have left behind */
+            STAMP(L, 13);
+            if (WAVES == 2 && !st && x >= 2) st = lds_wait(&L.f_wdone, x - 1, &L.f_stop);
+            STAMP(L, 23);
+            if (!st) row_prefetch(L, G, RT, row, x);
+            STAMP(L, 0);
+            /* ... so that their latency overlaps with the wait for the row above */
+            if (!st && seen < need)
+            {
+                st = poll_progress(C.progress + (row - 1), need, seen, G.spin_limit);
+                if (!st) consumer_acquire();
+            }
+            STAMP(L, 13);
+            if (!st) load_top(L, L.mb[x & 1], G, C.bottom + (size_t)(row - 1)*G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, row > row0);
+            /* two waves: the search of x starts from the predictor context the decision of x - 1 leaves behind */
+            STAMP(L, 0);
+            if (WAVES == 2 && !st && x >= 1) st = lds_wait(&L.f_decided, x, &L.f_stop);
+            STAMP(L, 6);
+            if (st)
+            {
+                /* stop: leave poison in this row's counter so everything behind it stops too (-1 failure, -2 abort); with two waves the
+                 * reconstruction wave is the one that publishes, so it also leaves the poison (after what it is publishing right now) */
+                if (WAVES == 2) { flag_set(&L.f_stop, st); return; }
+                if (LANE == 0)
+                {
+                    if (st == -1) *errflag = 1;
+                    __hip_atomic_store(my_progress, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 return;
             }
+            if (WAVES == 1) row_step<NARROW>(L, G, C, RT, row, x, row0, row1);
+            else mb_search<NARROW>(L, L.mb[x & 1], G, RT, row, x, row0, [&]() { flag_set(&L.f_noskip, x + 1); });
+            {
+                /* a far reference read of this macroblock waited in vain (rv_wait_rect): what it encoded is not trustworthy */
+                const int ff = uni(L.far_fail[0]) | (WAVES == 1 ? uni(L.far_fail[1]) : 0);
+                if (ff)
+                {
+                    if (WAVES == 2) { flag_set(&L.f_stop, ff < -2 ? -2 : ff); return; }
+                    if (LANE == 0)
+                    {
+                        if (ff == -1) *errflag = 1;
+                        __hip_atomic_store(my_progress, ff < -2 ? -2 : ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    return;
+                }
+            }
+            if (WAVES == 2) { flag_set(&L.f_inter, x + 1); STAMP(L, 14); continue; }
+            /* producer: every handed-off byte was stored write-through (sc1, wave.h cstore*): drain them, then the counter --
+             * no agent-scope release (L2 write-back) needed */
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (LANE == 0) __hip_atomic_store(my_progress, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            STAMP(L, 14);
         }
-        /* producer: every handed-off byte was stored write-through (sc1, wave.h cstore*): drain them, then the counter --
-         * no agent-scope release (L2 write-back) needed */
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(C.progress + row, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        STAMP(L, 14);
+        if (WAVES == 2)
+        {
+#ifdef H264E_STAMPS
+            if (LANE < 32 && C.prof) atomicAdd(C.prof + LANE, L.prof[0][LANE]);
+#endif
+            return;
+        }
+    } else
+    {
+        /* ---- the reconstruction wave of the two-wave pipeline: intra candidates + decision of x, then transform / CAVLC / deblocking /
+         * stores of x while the search wave is already on x + 1 */
+        for (int x = 0; x < G.nmbx; x++)
+        {
+            MbBuf &B = L.mb[x & 1];
+            MbCtx m;
+            mb_ctx_init<NARROW>(m, L, G, RT, row, x, row0, 1);
+            int ff = 0;
+            if (!mb_intra_decide(L, B, m, RT, InterFromSearchWave{ &L, x + 1 })) ff = uni(flag_get(&L.f_stop));
+            else
+            {
+                flag_set(&L.f_decided, x + 1);
+                mb_recon_write<NARROW>(L, B, m, G, C, RT, row, x, row0, row1);
+                ff = uni(L.far_fail[1]);
+                if (ff) { ff = ff < -2 ? -2 : ff; flag_set(&L.f_stop, ff); }
+            }
+            if (ff)
+            {
+                if (LANE == 0)
+                {
+                    if (ff == -1) *errflag = 1;
+                    __hip_atomic_store(my_progress, ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (LANE == 0) __hip_atomic_store(my_progress, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag_set(&L.f_wdone, x + 1);
+            STAMP(L, 14);
+        }
     }
     row_end(L, G, C, row);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(C.progress + row, G.nmbx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* row buffer + meta complete */
+    __builtin_amdgcn_wave_barrier();
+    if (LANE == 0) __hip_atomic_store(my_progress, G.nmbx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   /* row buffer + meta complete */
 }
 
 #endif
@@ -461,7 +570,7 @@ DEV void stage_selftest(StageLds &S, RowLds &L, int stage, const GLOBAL_AS uint8
         m.lambda_mv = k_lambda_mv_q4[a[9]];
         m.rv = R; m.rv.P = P8; m.rv.nmbx = 6; m.rv.nmby = 6;
         if (a[19]) { m.rv.has_win = 1; m.rv.win = (const lu8 *)L.win; m.rv.wx0 = 32 - WIN_M; m.rv.wy0 = 32 - WIN_M; wave_load_window(L.win, P8, m.rv.wx0, m.rv.wy0, 0); }
-        WAVE_FOR(l) { lds32_store(L.inp + 4*l, gload32((const gu8 *)in + 96*96 + 4*l)); lds32_store(L.gtest[0] + 4*l, 0u); }
+        WAVE_FOR(l) { lds32_store(L.mb[0].inp + 4*l, gload32((const gu8 *)in + 96*96 + 4*l)); lds32_store(L.gtest[0] + 4*l, 0u); }
         wave_sync();
         const rect_t range = { a[11], a[12], a[13], a[14] };
         /* the search is lane-group code (wave.h): group a[20] runs it, the other three idle */
@@ -470,7 +579,7 @@ DEV void stage_selftest(StageLds &S, RowLds &L, int stage, const GLOBAL_AS uint8
             if (grp == (a[20] & 3))
             {
                 mv32 mv = mvmk(a[4], a[5]);
-                const int cost = diamond_g(L, m, a[0], a[1], mv, range, mvmk(a[6], a[7]), a[8], a[2], a[3], L.gtest[0] + 16*a[1] + a[0], L.gscr);
+                const int cost = diamond_g(L, L.mb[0], m, a[0], a[1], mv, range, mvmk(a[6], a[7]), a[8], a[2], a[3], L.gtest[0] + 16*a[1] + a[0], L.gscr);
                 L.gcost[0] = cost; L.gcost[1] = mvx(mv); L.gcost[2] = mvy(mv);
             }
         }
@@ -610,6 +719,7 @@ struct h264e_hip_pool
     int *ref_sel;                        /* per chain */
     int ring_pos, pending;
     int profile, prof_launches;
+    int waves;                           /* wavefronts per macroblock row forced by H264E_WAVES (1 or 2); 0 = chosen per launch (h264e_hip_submit) */
     int test_upload_fail_at, async_uploads;     /* fault injection (H264E_TEST_KNOBS): the n-th asynchronous upload of this pool fails */
     double prof_mb_ms, prof_splice_ms;
 #ifndef H264E_EMU
@@ -762,6 +872,8 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         if (getenv("H264E_TEST_UPLOAD_FAIL_AT")) p->test_upload_fail_at = atoi(getenv("H264E_TEST_UPLOAD_FAIL_AT"));
     }
     p->frame_bytes = (size_t)width*height*3/2;
+    p->waves = getenv("H264E_WAVES") ? atoi(getenv("H264E_WAVES")) : 0;                  /* 1 / 2: forced (A-B measurements); else chosen per launch */
+    if (p->waves < 0 || p->waves > 2) p->waves = 0;
 #ifndef H264E_EMU
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -1087,7 +1199,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     if (p->pending >= TASK_RING - 1 && h264e_hip_sync(p)) return -1;
     h264e_frame_task_t *host = (h264e_frame_task_t *)calloc((size_t)p->nchains, sizeof(h264e_frame_task_t));
     if (!host) FAIL("out of host memory");
-    int any = 0, any_narrow = 0, any_wide = 0, njobs = 0;
+    int any = 0, any_narrow = 0, any_wide = 0, njobs = 0, all_intra = 1;
     const int launch_id = ++p->launch_counter;
     for (int c = 0; c < p->nchains; c++)
     {
@@ -1102,6 +1214,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             FAIL("submit: bad task for chain %d", c);
         }
         any = 1; njobs = c + 1;
+        if (t.slice_type != 2) all_intra = 0;
         const uint8_t *f = p->clip + p->frame_bytes*(size_t)t.frame_index;
         d.in[0] = f; d.in[1] = f + (size_t)G.width*G.height; d.in[2] = d.in[1] + (size_t)(G.width/2)*(G.height/2);
         d.in_stride[0] = G.width; d.in_stride[1] = d.in_stride[2] = G.width/2;
@@ -1296,12 +1409,26 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     }
     const int pe = p->ev_pending;
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][0], p->stream));
-    if (any_narrow)
-        hipLaunchKernelGGL(h264e_mb_kernel<true>, dim3((unsigned)(njobs*(G.nmby + 1))), dim3(64), 0, p->stream,
-                           G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, (const uint32_t *)p->order, p->errflag, p->stepflags);
-    else
-        hipLaunchKernelGGL(h264e_mb_kernel<false>, dim3((unsigned)(njobs*(G.nmby + 1))), dim3(64), 0, p->stream,
-                           G, (const h264e_chain_dev_t *)p->chains_dev, (const h264e_frame_task_t *)slot, (const uint32_t *)p->order, p->errflag, p->stepflags);
+    {
+        const dim3 grid((unsigned)(njobs*(G.nmby + 1)));
+        const h264e_chain_dev_t *cd = p->chains_dev;
+        const h264e_frame_task_t *td = slot;
+        const uint32_t *od = p->order;
+        /* wavefronts per macroblock row: two (search | reconstruction pipeline) halve the macroblock latency for twice the wave slots --
+         * the better trade wherever a launch is latency bound (single-slice streams: mis-speculation events; rate control and the
+         * frame-at-a-time API: a few frames per launch) and still level for multi-slice streams; an all-intra launch has nothing to
+         * search and no events: one wave per row, twice the rows in flight (19.3 vs 16.1 M MB/s at 1080p) */
+        const int waves = p->waves ? p->waves : all_intra ? 1 : 2;
+        if (waves == 2)
+        {
+            if (any_narrow) hipLaunchKernelGGL((h264e_mb_kernel<true, 2>), grid, dim3(128), 0, p->stream, G, cd, td, od, p->errflag, p->stepflags);
+            else hipLaunchKernelGGL((h264e_mb_kernel<false, 2>), grid, dim3(128), 0, p->stream, G, cd, td, od, p->errflag, p->stepflags);
+        } else
+        {
+            if (any_narrow) hipLaunchKernelGGL((h264e_mb_kernel<true, 1>), grid, dim3(64), 0, p->stream, G, cd, td, od, p->errflag, p->stepflags);
+            else hipLaunchKernelGGL((h264e_mb_kernel<false, 1>), grid, dim3(64), 0, p->stream, G, cd, td, od, p->errflag, p->stepflags);
+        }
+    }
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][1], p->stream));
     HIPCHK(hipGetLastError());
     if (p->profile)

@@ -24,6 +24,7 @@
 #define LDS_AS
 #define NOINLINE_DEV static __attribute__((noinline))
 #define DEV static inline
+#define DEVM inline                     /* member functions */
 #define DCONST static const
 #ifdef H264E_EMU_REVERSE      /* run lanes in the opposite order: catches code that leaks a lane-private value */
 #define WAVE_FOR(l) for (int l = 63; l >= 0; --l)
@@ -120,12 +121,15 @@ DEV void grp_count(int *p) { *p += 1; }
 #else /* device build */
 
 #include <hip/hip_runtime.h>
+/* lane of the wavefront: a workgroup is ONE wavefront (64 threads) or, in the two-wave pipeline, two wavefronts with different jobs */
+#define LANE ((int)(threadIdx.x & 63u))
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 #define NOINLINE_DEV static __device__ __noinline__
 #define DEV static __device__ __forceinline__
+#define DEVM __device__ __forceinline__
 #define DCONST static __device__ const
-#define WAVE_FOR(l) for (int l = (int)threadIdx.x, _w1 = 1; _w1; _w1 = 0)
+#define WAVE_FOR(l) for (int l = LANE, _w1 = 1; _w1; _w1 = 0)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 /* Single-wave workgroup: LDS operations of one wavefront execute in program order, so making one lane's LDS
  * store visible to another lane only needs the COMPILER to keep the order: a wavefront-scope fence (no
@@ -135,7 +139,7 @@ DEV void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-DEV int wave_lane() { return (int)threadIdx.x; }
+DEV int wave_lane() { return LANE; }
 /* a value every lane holds identically: move it to a scalar register so the control code runs on the scalar unit */
 DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 /* sum over the 64 lanes: DPP inside rows of 16 (quad swaps, half-row and row mirror), then 4 v_readlane */
@@ -148,11 +152,11 @@ DEV int wave_reduce_add(int v)
     return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
-template <class F> DEV int wave_sum(F f) { return wave_reduce_add(f((int)threadIdx.x)); }
+template <class F> DEV int wave_sum(F f) { return wave_reduce_add(f(LANE)); }
 template <class F> DEV void wave_sum4(F f, int out[4])
 {
     int v[4] = { 0, 0, 0, 0 };
-    f((int)threadIdx.x, v);
+    f(LANE, v);
     /* partial sums stay below 2^16 for every caller (<= 64 lanes x 4 x 255): reduce two per register */
     int a = v[0] | (v[1] << 16), b = v[2] | (v[3] << 16);
     a = wave_reduce_add(a);
@@ -163,7 +167,7 @@ template <class F> DEV void wave_sum4(F f, int out[4])
 template <class F> DEV void wave_sum8(F f, int out[8])
 {
     int v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    f((int)threadIdx.x, v);
+    f(LANE, v);
 #pragma unroll
     for (int k = 0; k < 4; k++)
     {
@@ -171,7 +175,7 @@ template <class F> DEV void wave_sum8(F f, int out[8])
         out[2*k] = a & 0xffff; out[2*k + 1] = (int)((unsigned)a >> 16);
     }
 }
-template <class F> DEV uint64_t wave_ballot(F f) { return __ballot(f((int)threadIdx.x)); }
+template <class F> DEV uint64_t wave_ballot(F f) { return __ballot(f(LANE)); }
 DEV uint32_t sad4_u8(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
 DEV int clz32(uint32_t v) { return __clz((int)v); }
 DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
@@ -184,8 +188,8 @@ DEV uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
  * (DPP inside the row: every lane of the group receives the sum); nothing in a group section may use the wave-level primitives
  * above (uni, wave_sum, LaneArr: they would mix the groups).
  */
-#define GRP_EACH(g) for (int g = (int)threadIdx.x >> 4, _e1 = 1; _e1; _e1 = 0)
-#define GRP_FOR(i) for (int i = (int)threadIdx.x & 15, _g1 = 1; _g1; _g1 = 0)
+#define GRP_EACH(g) for (int g = LANE >> 4, _e1 = 1; _e1; _e1 = 0)
+#define GRP_FOR(i) for (int i = LANE & 15, _g1 = 1; _g1; _g1 = 0)
 DEV int row_reduce_add(int v)
 {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);      /* quad_perm [1,0,3,2] */
@@ -194,11 +198,11 @@ DEV int row_reduce_add(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);     /* row_mirror */
     return v;
 }
-template <class F> DEV int grp_sum(F f) { return row_reduce_add(f((int)threadIdx.x & 15)); }
+template <class F> DEV int grp_sum(F f) { return row_reduce_add(f(LANE & 15)); }
 template <class F> DEV void grp_sum4(F f, int out[4])
 {
     int v[4] = { 0, 0, 0, 0 };
-    f((int)threadIdx.x & 15, v);
+    f(LANE & 15, v);
     /* sums stay below 2^16 for every caller (<= 256 samples x 255): two per register */
     const int a = row_reduce_add(v[0] | (v[1] << 16)), b = row_reduce_add(v[2] | (v[3] << 16));
     out[0] = a & 0xffff; out[1] = (int)((unsigned)a >> 16);
@@ -207,7 +211,7 @@ template <class F> DEV void grp_sum4(F f, int out[4])
 template <class F> DEV void grp_sum8(F f, int out[8])
 {
     int v[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    f((int)threadIdx.x & 15, v);
+    f(LANE & 15, v);
 #pragma unroll
     for (int k = 0; k < 4; k++)
     {
@@ -219,28 +223,29 @@ template <class F> DEV void grp_sum8(F f, int out[8])
  * quads, instead of four (eight) times in every lane */
 template <class F> DEV void grp_eval4(F f, int out[4])
 {
-    const int c = f((int)threadIdx.x & 3);
+    const int c = f(LANE & 3);
     out[0] = __builtin_amdgcn_update_dpp(0, c, 0x00, 0xf, 0xf, true); out[1] = __builtin_amdgcn_update_dpp(0, c, 0x55, 0xf, 0xf, true);
     out[2] = __builtin_amdgcn_update_dpp(0, c, 0xAA, 0xf, 0xf, true); out[3] = __builtin_amdgcn_update_dpp(0, c, 0xFF, 0xf, 0xf, true);
 }
 template <class F> DEV void grp_eval8(F f, int out[8])
 {
-    const int c0 = f((int)threadIdx.x & 3), c1 = f(4 + ((int)threadIdx.x & 3));
+    const int c0 = f(LANE & 3), c1 = f(4 + (LANE & 3));
     out[0] = __builtin_amdgcn_update_dpp(0, c0, 0x00, 0xf, 0xf, true); out[1] = __builtin_amdgcn_update_dpp(0, c0, 0x55, 0xf, 0xf, true);
     out[2] = __builtin_amdgcn_update_dpp(0, c0, 0xAA, 0xf, 0xf, true); out[3] = __builtin_amdgcn_update_dpp(0, c0, 0xFF, 0xf, 0xf, true);
     out[4] = __builtin_amdgcn_update_dpp(0, c1, 0x00, 0xf, 0xf, true); out[5] = __builtin_amdgcn_update_dpp(0, c1, 0x55, 0xf, 0xf, true);
     out[6] = __builtin_amdgcn_update_dpp(0, c1, 0xAA, 0xf, 0xf, true); out[7] = __builtin_amdgcn_update_dpp(0, c1, 0xFF, 0xf, 0xf, true);
 }
 /* a statistics counter in LDS, bumped once per group */
-DEV void grp_count(int *p) { if (((int)threadIdx.x & 15) == 0) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV void grp_count(int *p) { if ((LANE & 15) == 0) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
 
 /* diagnostic build only (-DH264E_STAMPS): cycle stamps per pipeline phase, accumulated in LDS (never in the product) */
 #if defined(H264E_STAMPS) && !defined(H264E_EMU)
-#define STAMP(L, id) do { unsigned long long t_ = __builtin_readcyclecounter(); (L).prof[id] += t_ - (L).prof_last; (L).prof_last = t_; } while (0)
-#define PCOUNT(L, id) do { (L).prof[id]++; } while (0)
+#define PROF_W ((int)(threadIdx.x >> 6))         /* every wavefront of the workgroup keeps its own stamps */
+#define STAMP(L, id) do { unsigned long long t_ = __builtin_readcyclecounter(); (L).prof[PROF_W][id] += t_ - (L).prof_last[PROF_W]; (L).prof_last[PROF_W] = t_; } while (0)
+#define PCOUNT(L, id) do { (L).prof[PROF_W][id]++; } while (0)
 #define PTIC() unsigned long long tic_ = __builtin_readcyclecounter()
-#define PTOC(L, id) do { (L).prof[id] += __builtin_readcyclecounter() - tic_; } while (0)
+#define PTOC(L, id) do { (L).prof[PROF_W][id] += __builtin_readcyclecounter() - tic_; } while (0)
 #else
 #define STAMP(L, id) do { } while (0)
 #define PCOUNT(L, id) do { } while (0)
@@ -263,8 +268,8 @@ struct LaneArr
 #else
     int r;
     __device__ __forceinline__ int get(int i) const { return __builtin_amdgcn_readlane(r, __builtin_amdgcn_readfirstlane(i)); }
-    __device__ __forceinline__ void set(int i, int v) { r = ((int)threadIdx.x == __builtin_amdgcn_readfirstlane(i)) ? __builtin_amdgcn_readfirstlane(v) : r; }    /* compare + select: no v_writelane builtin */
-    __device__ __forceinline__ int has(int v, int n) const { return __ballot((int)threadIdx.x < n && r == __builtin_amdgcn_readfirstlane(v)) != 0; }
+    __device__ __forceinline__ void set(int i, int v) { r = (LANE == __builtin_amdgcn_readfirstlane(i)) ? __builtin_amdgcn_readfirstlane(v) : r; }    /* compare + select: no v_writelane builtin */
+    __device__ __forceinline__ int has(int v, int n) const { return __ballot(LANE < n && r == __builtin_amdgcn_readfirstlane(v)) != 0; }
 #endif
 };
 
@@ -305,7 +310,7 @@ DEV void consumer_acquire()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 }
 #endif
 DEV void cstore32(gu8 *p, uint32_t v) { __hip_atomic_store((GLOBAL_AS uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

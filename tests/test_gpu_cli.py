@@ -62,7 +62,7 @@ def test_cli_clip_mode_and_quirks(app, tmp_path):
     assert r.returncode == 1 and b"cant open input file" in r.stdout
     # options of the reference (minih264e_test.c:135, :163) that this encoder does not implement: refused, never a different stream
     for opt in ("--denoise", "--gen"):
-        out.unlink()
+        out.unlink(missing_ok=True)
         r = _run(["--input", str(yuv), "--output", str(out), opt, "x"] + g["flags"].split(), str(tmp_path))
         assert r.returncode == 1 and b"not supported" in r.stdout and not out.exists(), r.stdout.decode()
 

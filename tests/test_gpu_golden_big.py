@@ -46,6 +46,9 @@ def test_full_length_stream_matches_reference(P, name):
     assert len(out) == g["bytes"] and hashlib.md5(out).hexdigest() == g["md5"]
     if name == "bench_1080p_600":
         assert st.reencoded_gops >= 10, "the bench stream no longer exercises the relaunch path"
+    if name in ("4k_240", "8k_35"):
+        # 4K / 8K single slice at lengths that reach the abort / relaunch path, slot reuse and GOP boundaries at those geometries
+        assert st.reencoded_gops >= 1, "%s no longer exercises the relaunch path" % name
 
 
 @pytest.mark.parametrize("name,max_chains", [("bench_1080p_600", 64), ("bench_1080p_600_thr8", 40), ("cif_300_gop30", 16), ("1080p_30_kbps", 3)])

@@ -15,10 +15,14 @@ echo "tests rc=$rc" | tee -a $OUT/tests.log
 tail -5 $OUT/tests.log
 [ $rc -ne 0 ] && exit $rc
 export H264E_QUIET=1
-for cfg in "600 1920 1080 30 26 0 0" "600 1920 1080 30 26 8 0" "600 1920 1080 1 26 0 0" ${EXTRA_CFGS}; do
-  timeout -k 10 200 python tools/clip_debug.py $cfg 2>/dev/null | tail -1 >> $OUT/configs.txt || exit 1
+for wv in 2 1; do
+  export H264E_WAVES=$wv
+  echo "--- H264E_WAVES=$wv" >> $OUT/configs.txt
+  for cfg in "600 1920 1080 30 26 0 0" "600 1920 1080 30 26 8 0" "600 1920 1080 1 26 0 0" ${EXTRA_CFGS}; do
+    timeout -k 10 200 python tools/clip_debug.py $cfg 2>/dev/null | tail -1 >> $OUT/configs.txt || exit 1
+  done
+  timeout -k 10 120 python tools/single_frame_latency.py >> $OUT/configs.txt 2>&1 || exit 1
 done
 cat $OUT/configs.txt
-timeout -k 10 120 python tools/single_frame_latency.py > $OUT/lone.txt 2>&1 || exit 1; cat $OUT/lone.txt
-timeout -k 10 300 python tools/phase_profile.py 600 1920 1080 30 > $OUT/phase600.txt 2>&1 || exit 1
+H264E_WAVES=1 timeout -k 10 300 python tools/phase_profile.py 600 1920 1080 30 > $OUT/phase600.txt 2>&1 || exit 1
 cat $OUT/phase600.txt

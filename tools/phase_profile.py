@@ -10,9 +10,12 @@ sys.path.insert(0, ROOT)
 os.environ["H264E_LIB"] = os.path.join(ROOT, "h264-lab_amd", "lib", "libh264e_mi355x_stamps.so")
 from __graft_entry__ import _pkg  # noqa: E402
 
-NAMES = {0: "setup", 1: "load top+input", 2: "inter: predictors", 3: "inter: skip test", 4: "inter: candidates", 5: "inter: diamond full-pel",
-         6: "inter: sub-pel", 7: "inter: partition loop rest", 8: "intra 16x16", 9: "intra 4x4", 10: "chroma prediction", 11: "mb_write (xform/quant/CAVLC/recon)",
-         12: "ctx save + deblock + stores", 13: "WAIT for row above (poll+acquire)", 14: "publish (drain stores)"}
+NAMES = {0: "S load input + window + records above", 1: "S setup", 2: "S inter: predictors", 3: "S inter: skip test", 4: "S inter: candidates", 5: "S inter: partition search (4 lane groups)",
+         7: "S inter: rest", 13: "S WAIT row above / reference frame (poll+acquire)", 23: "S wait: hand-off buffer free (R wave 2 MBs behind)", 6: "S wait: decision of x-1 (R wave)",
+         15: "R wait: search wave's skip test", 8: "R intra 16x16", 9: "R intra 4x4", 16: "R wait: inter decision", 10: "R merge + contexts + chroma prediction",
+         11: "R mb_write (xform/quant/CAVLC/recon)", 12: "R ctx save + deblock + stores", 14: "publish / signal"}
+ORDER = [13, 23, 0, 6, 1, 2, 3, 4, 5, 7, 15, 8, 9, 16, 10, 11, 12, 14]
+SEARCH_SIDE = {13, 23, 0, 6, 1, 2, 3, 4, 5, 7}
 
 
 def main():
@@ -29,25 +32,23 @@ def main():
     t = (C.c_ulonglong * 32)()
     L.H264E_clip_stamps(ce.c, t)
     nmb = sum(t[20:23])
-    tot = sum(t[i] for i in range(15))
-    print("%dx%d %d frames gop %d: %d MBs (skip %d, inter %d, intra %d); mb kernel %.1f ms over %d launches" %
-          (w, h, frames, gop, nmb, t[20], t[21], t[22], st.mb_kernel_ms, st.kernel_launches))
-    print("%-42s %12s %8s %10s" % ("phase", "cycles/MB", "share", "us/MB@2.1G"))
-    for i in range(15):
-        print("%-42s %12.0f %7.1f%% %10.2f" % (NAMES[i], t[i] / nmb, 100.0 * t[i] / tot, t[i] / nmb / 2100.0))
-    print("%-42s %12.0f %8s %10.2f" % ("total", tot / nmb, "", tot / nmb / 2100.0))
+    tot = sum(t[i] for i in ORDER)
+    print("%dx%d %d frames gop %d: %d MBs (skip %d, inter %d, intra %d); mb kernel %.1f ms over %d launches; H264E_WAVES=%s" %
+          (w, h, frames, gop, nmb, t[20], t[21], t[22], st.mb_kernel_ms, st.kernel_launches, os.environ.get("H264E_WAVES", "auto")))
+    print("S = search side (with two waves per row: the search wave), R = reconstruction side (the reconstruction wave)")
+    print("%-58s %12s %8s" % ("phase", "cycles/MB", "share"))
+    for i in ORDER:
+        print("%-58s %12.0f %7.1f%%" % (NAMES[i], t[i] / nmb, 100.0 * t[i] / tot))
+    s_tot = sum(t[i] for i in ORDER if i in SEARCH_SIDE)
+    print("%-58s %12.0f" % ("total search side", s_tot / nmb))
+    print("%-58s %12.0f" % ("total reconstruction side", (tot - s_tot) / nmb))
     if t[18]:
-        print("diamond calls/MB %.2f  scan iterations/call %.1f  SAD batches/call %.2f  cycles/batch %.0f  cycles/diag-probe-phase per call %.0f" %
-              (t[18] / nmb, t[19] / t[18], t[17] / t[18], t[16] / max(t[17], 1), t[23] / t[18]))
-        if t[15]:
-            print("diamond: entry..end of the full-pel search %.0f cycles per call (incl. batches and the diagonal probe)" % (t[15] / t[18]))
+        print("partition searches (serial steps of the lane groups)/MB %.2f  scan iterations/step %.1f  SAD batches/step %.2f" % (t[18] / nmb, t[19] / t[18], t[17] / t[18]))
     if t[30]:
         print("mb_write: luma transform + quantiser + reconstruction %.0f cycles/MB (of the mb_write line above; the CAVLC of the residual blocks measured 2.3 k)" % (t[30] / nmb))
     if t[29]:
         print("effective shader clock over the rows' lifetimes: %.0f MHz (cycle counter / 100 MHz wall clock)" % (100.0 * t[28] / t[29]))
-    if t[24] or t[25]:
-        print("cycles per macroblock by type: skip %.0f  inter %.0f  intra %.0f;  partition set-up before each diamond call %.0f" %
-              (t[24] / max(t[20], 1), t[25] / max(t[21], 1), t[26] / max(t[22], 1), t[27] / max(t[18], 1)))
+
 
 
 if __name__ == "__main__":
