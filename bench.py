@@ -37,13 +37,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # algorithmic bytes per macroblock: input 384 B; P frames also read the co-located reference
 # (384 B); every frame writes 384 B of reconstruction
 READ_I, READ_P, WRITE = 384, 768, 384
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 def _pmc_traffic():
     """HBM bytes per h264e_mb_kernel launch from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate
     runs of this same command; the json says how they were taken).  STATIC: read from profiles/, not measured in this run."""
-    for tag in (PROFILE_TAG, "r01"):
+    for tag in (PROFILE_TAG, "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)) as f:
                 return json.load(f)["bytes_per_launch"], "static_from_profiles/%s_pmc_traffic.json" % tag
@@ -54,7 +54,7 @@ def _pmc_traffic():
 
 def _issue_counters():
     """SQ instruction counters of the committed profile (tools/pmc_insts.sh), for the issue roofline; static like the traffic"""
-    for tag in (PROFILE_TAG, "r01"):
+    for tag in (PROFILE_TAG, "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_sq_counters.json" % tag)) as f:
                 return json.load(f), "static_from_profiles/%s_sq_counters.json" % tag

@@ -830,6 +830,38 @@ DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_
     return bm + (best_sad << 4);
 }
 
+/* ------------------------------------------------------------------ 4x4 transforms in registers (V16 tiles, wave.h) */
+
+/* one pass of the forward core transform (H:2385-2409) along the quads: d0..d3 at quad positions 0..3 -> outputs k = 0..3 */
+DEV V16 v16_fwd_quad(const V16 &d)
+{
+    const V16 p = v16_quadperm<3, 2, 1, 0>(d);
+    const V16 u = v16_map2(d, p, [](int i, int a, int b) -> int { return (i & 2) ? b - a : a + b; });        /* t0 = d0+d3, t2 = d1+d2, t3 = d1-d2, t1 = d0-d3 */
+    const V16 A = v16_quadperm<0, 3, 0, 3>(u), Bq = v16_quadperm<1, 2, 1, 2>(u);                               /* t0 t1 t0 t1 | t2 t3 t2 t3 */
+    return v16_map2(A, Bq, [](int i, int a, int b) -> int { const int x = i & 3; return x == 0 ? a + b : x == 1 ? 2*a + b : x == 2 ? a - b : a - 2*b; });
+}
+/* residual in lane 4*y + x -> coefficient in lane 4*k_h + k_v, the reference's storage order (H:2374-2409: rows, then columns; no
+ * rounding anywhere and every intermediate fits int16, so the pass order does not matter) */
+DEV V16 v16_fwd4x4(const V16 &d) { return v16_fwd_quad(v16_xpose(v16_fwd_quad(d))); }
+
+/* one pass of the inverse transform (H:2436-2489) along the quads, before the int16 truncation of its results */
+DEV V16 v16_inv_quad(const V16 &c)
+{
+    const V16 p = v16_quadperm<2, 3, 0, 1>(c);
+    const V16 u = v16_map2(c, p, [](int i, int d, int q) -> int { const int x = i & 3; return x == 0 ? d + q : x == 1 ? (d >> 1) - q : x == 2 ? q - d : q + (d >> 1); });   /* e0 e2 e1 e3 */
+    const V16 A = v16_quadperm<0, 2, 2, 0>(u), Bq = v16_quadperm<3, 1, 1, 3>(u);                               /* e0 e1 e1 e0 | e3 e2 e2 e3 */
+    return v16_map2(A, Bq, [](int i, int a, int b) -> int { return (i & 2) ? a - b : a + b; });
+}
+/* dequantized coefficient in lane 4*k_h + k_v -> the residual sample (x, y) in lane 4*x + y (TRANSPOSED: callers address with
+ * x = i >> 2, y = i & 3), in the reference's pass order (over k_h first, int16 between the passes, H:2436-2489), rounded: (v + 32) >> 6
+ * truncated to int16 like H:2478 */
+DEV V16 v16_inv4x4(const V16 &c)
+{
+    const V16 f = v16_map(v16_inv_quad(v16_xpose(c)), [](int, int v) -> int { return (int16_t)v; });          /* lane 4*k_v + x */
+    const V16 g = v16_inv_quad(v16_xpose(f));                                                                   /* lane 4*x + y */
+    return v16_map(g, [](int, int v) -> int { return (int16_t)((v + 32) >> 6); });
+}
+
 /* ------------------------------------------------------------------ transform / quant */
 
 /*
@@ -841,32 +873,15 @@ DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_
 DEV unsigned wave_xform_quant(const uint8_t *inp, const uint8_t *pred, int mode, qblk_t *q, int16_t *dc, const uint16_t *qdat)
 {
     const int n = mode >> 1, i0 = mode & 1, nb = n*n;
-    /* forward transform (H:2374-2409): every lane produces one coefficient (kh,kv) of its block: the four row
-     * butterflies, select output kh, then the column butterfly, select output kv.  No rounding anywhere and all
-     * intermediates fit int16, so this equals the reference's two-pass butterflies. */
-    for (int pass = 0; pass*64 < nb*16; pass++)
+    /* forward transform (H:2374-2409) in registers, one block per 16-lane tile (wave.h V16): four blocks per pass */
+    for (int pass = 0; pass*V16_TILES < nb; pass++)
     {
-        WAVE_FOR(l)
-        {
-            const int idx = pass*64 + l, b = idx >> 4, i = idx & 15;
-            if (b < nb)
-            {
-                const int kh = i >> 2, kv = i & 3, bx = b & (n - 1), by = b >> (n >> 1);      /* n is 1, 2 or 4 */
-                const uint8_t *pi = inp + 64*by + 4*bx, *pp = pred + 64*by + 4*bx;
-                int rr[4];
-#pragma unroll
-                for (int y = 0; y < 4; y++)
-                {
-                    const uint32_t a = lds32(pi + 16*y), c = lds32(pp + 16*y);
-                    const int d0 = (int)(a & 255) - (int)(c & 255), d1 = (int)((a >> 8) & 255) - (int)((c >> 8) & 255);
-                    const int d2 = (int)((a >> 16) & 255) - (int)((c >> 16) & 255), d3 = (int)(a >> 24) - (int)(c >> 24);
-                    const int t0 = d0 + d3, t1 = d0 - d3, t2 = d1 + d2, t3 = d1 - d2;
-                    rr[y] = kh == 0 ? t0 + t2 : kh == 1 ? 2*t1 + t3 : kh == 2 ? t0 - t2 : t1 - 2*t3;
-                }
-                const int t0 = rr[0] + rr[3], t1 = rr[0] - rr[3], t2 = rr[1] + rr[2], t3 = rr[1] - rr[2];
-                q[b].dq[i] = (int16_t)(kv == 0 ? t0 + t2 : kv == 1 ? 2*t1 + t3 : kv == 2 ? t0 - t2 : t1 - 2*t3);
-            }
-        }
+        const V16 d = v16_make([&](int i, int tile) -> int {
+            const int b = imin(pass*V16_TILES + tile, nb - 1), bx = b & (n - 1), by = b >> (n >> 1), o = 64*by + 4*bx + 16*(i >> 2) + (i & 3);      /* n is 1, 2 or 4 */
+            return (int)inp[o] - (int)pred[o];
+        });
+        const V16 c = v16_fwd4x4(d);
+        v16_each(c, [&](int i, int tile, int v) { const int b = pass*V16_TILES + tile; if (b < nb) q[b].dq[i] = (int16_t)v; });
     }
     wave_sync();
     if (i0)
@@ -929,6 +944,31 @@ DEV unsigned wave_xform_quant(const uint8_t *inp, const uint8_t *pred, int mode,
     unsigned mask = 0;
     for (int b = 0; b < nb; b++) mask = (mask << 1) | ((nzbits >> b) & 1);
     return mask;
+}
+
+/*
+ * One intra 4x4 block behind its mode decision (H:4790-4811): residual of the input block `bin` (stride 16) against the
+ * prediction `pred` (stride 16), forward transform, quantisation (H:2536-2597, no dead zone for intra blocks), inverse transform and
+ * reconstruction into `rec` (stride rs) -- all in the registers of one 16-lane tile.  Leaves levels and dequantized coefficients in
+ * q (mb_write codes the levels when the macroblock ends up intra 4x4).  Returns 1 when a level is non-zero.
+ */
+DEV unsigned i4_block_code(const uint8_t *bin, const uint8_t *pred, uint8_t *rec, int rs, qblk_t *q, const uint16_t *qdat)
+{
+    const V16 d = v16_make([&](int i, int) -> int { return (int)bin[16*(i >> 2) + (i & 3)] - (int)pred[16*(i >> 2) + (i & 3)]; });
+    const V16 c = v16_fwd4x4(d);
+    const int rnd = qdat[QD_RND];
+    const V16 lev = v16_map(c, [&](int i, int v) -> int {
+        const int off = ((i & 1) + ((i >> 2) & 1))*2;            /* H:2366 g_idx2quant */
+        return (v*(int)qdat[off] + (v < 0 ? 0xFFFF - rnd : rnd)) >> 16;
+    });
+    const V16 deq = v16_map(lev, [&](int i, int v) -> int { return (int16_t)(v*(int)qdat[((i & 1) + ((i >> 2) & 1))*2 + 1]); });
+    v16_each(lev, [&](int i, int, int v) { q->qv[i] = (int16_t)v; });
+    v16_each(deq, [&](int i, int, int v) { q->dq[i] = (int16_t)v; });
+    const unsigned coded = v16_nonzero_mask(v16_map(lev, [](int, int v) -> int { return (int16_t)v; })) != 0;
+    const V16 r = v16_inv4x4(deq);
+    v16_each(r, [&](int i, int, int v) { const int x = i >> 2, y = i & 3; rec[rs*y + x] = (uint8_t)clip255(v + (int)pred[16*y + x]); });
+    wave_sync();
+    return coded;
 }
 
 /* H:2269-2301 hadamar4_2d (result transposed, every store truncated to int16); uniform, in place */
@@ -1001,32 +1041,22 @@ DEV int quant_chroma_dc(qblk_t *q, int16_t *dc, int16_t *lev, const uint16_t *qd
 DEV void wave_recon(uint8_t *out, int os, const uint8_t *pred, const qblk_t *q, int side, uint32_t mask)
 {
     const int nb = side*side;
-    for (int pass = 0; pass*64 < nb*16; pass++)
+    for (int pass = 0; pass*V16_TILES < nb; pass++)
     {
-        WAVE_FOR(l)
-        {
-            int idx = pass*64 + l, b = idx >> 4, i = idx & 15;
+        /* one block per 16-lane tile; v16_inv4x4 leaves sample (x, y) in lane 4*x + y */
+        const V16 c = v16_make([&](int i, int tile) -> int {
+            const int b = imin(pass*V16_TILES + tile, nb - 1);
+            return ((mask << b) & 0x80000000u) ? (int)q[b].dq[i] : 0;
+        });
+        const V16 r = v16_inv4x4(c);
+        v16_each(r, [&](int i, int tile, int v) {
+            const int b = pass*V16_TILES + tile;
             if (b < nb)
             {
-                int x = i & 3, y = i >> 2, bx = b & (side - 1), by = b >> (side >> 1);          /* side is 1, 2 or 4 */
-                int v = pred[64*by + 4*bx + 16*y + x];
-                if ((mask << b) & 0x80000000u)
-                {
-                    const int16_t *c = q[b].dq;
-                    int f[4];
-                    for (int kv = 0; kv < 4; kv++)      /* horizontal pass: sample x of row kv */
-                    {
-                        int d0 = c[kv], d1 = c[kv + 4], d2 = c[kv + 8], d3 = c[kv + 12];
-                        int e0 = d0 + d2, e1 = d0 - d2, e2 = (d1 >> 1) - d3, e3 = d1 + (d3 >> 1);
-                        f[kv] = (int16_t)(x == 0 ? e0 + e3 : x == 1 ? e1 + e2 : x == 2 ? e1 - e2 : e0 - e3);
-                    }
-                    int g0 = f[0] + f[2], g1 = f[0] - f[2], g2 = (f[1] >> 1) - f[3], g3 = f[1] + (f[3] >> 1);
-                    int hh = y == 0 ? g0 + g3 : y == 1 ? g1 + g2 : y == 2 ? g1 - g2 : g0 - g3;
-                    v = clip255((int16_t)((hh + 32) >> 6) + v);
-                }
-                out[(size_t)(4*by + y)*os + 4*bx + x] = (uint8_t)v;
+                const int x = i >> 2, y = i & 3, bx = b & (side - 1), by = b >> (side >> 1);          /* side is 1, 2 or 4 */
+                out[(size_t)(4*by + y)*os + 4*bx + x] = (uint8_t)clip255(v + (int)pred[64*by + 4*bx + 16*y + x]);      /* no coded coefficients: v = 0, the prediction */
             }
-        }
+        });
     }
     wave_sync();
 }

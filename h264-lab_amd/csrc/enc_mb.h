@@ -67,7 +67,8 @@ struct RowLds
     int16_t slice_row[H264E_MAX_SLICES + 2];       /* this frame's slice start rows (copy of the task's) */
     unsigned long long prof[2][32], prof_last[2], prof_c0, prof_w0;     /* -DH264E_STAMPS diagnostic build only */
     /* hand-off words of the two-wave pipeline (h264e_kernels.hip): monotonic counters "macroblocks done" per stage, and a stop code */
-    int f_loaded, f_noskip, f_inter, f_decided, f_wdone, f_stop;
+    int f_noskip, f_bound, f_inter, f_decided, f_wdone, f_stop;
+    int early_bound;                                /* an upper bound of the inter cost, known right after the candidate evaluation (f_bound) */
 
     MbBuf mb[2];
 
@@ -331,6 +332,7 @@ DEV int diamond_g(RowLds &L, const MbBuf &B, const MbCtx &m, int px, int py, mv3
         break;
     }
     const uint32_t c0 = CGET(cur, 0), c1 = CGET(cur, 1), c2 = CGET(cur, 2), c3 = CGET(cur, 3);
+    STAMP(L, 25);
 #undef CGET
 #undef CSET
 #undef DX
@@ -418,6 +420,7 @@ DEV int diamond_g(RowLds &L, const MbBuf &B, const MbCtx &m, int px, int py, mv3
         wave_sync();
         mv = vbest;
     }
+    STAMP(L, 26);
     return min_sad;
 }
 
@@ -448,12 +451,14 @@ DEV void search_type(RowLds &L, const MbBuf &B, const MbCtx &m, int t, mv32 mv_b
             sad_best = grp_sad_ref(m.rv, px + (mvx(mvabs) >> 2), py + (mvy(mvabs) >> 2), B.inp + 16*py + px, w, h)
                      + mv_cost(m, mvabs, mb_abs(m, mvp));
         }
+        STAMP(L, 24);
         part_sad += diamond_g(L, B, m, px, py, mvabs, range, mb_abs(m, mvp), sad_best, w, h, test + 16*py + px, scr);
         const mv32 mv = mvsub(mvabs, mvmk(m.x*64, m.y*64));
         L.part_mvd[t][imv] = mvsub(mv, mvp);
         L.part_mv[t][imv++] = mv;
         mvp_put_arr(X.mv_left, X.mv_tl, X.mv_top, px >> 2, py >> 2, w >> 2, h >> 2, mv);
         wave_sync();
+        STAMP(L, 27);
         px = (px + w) & 15;
         if (!px)
         {
@@ -518,7 +523,9 @@ DEV int skip_chroma_ok(const MbBuf &B, const MbCtx &m, const uint8_t *pred_c)
 }
 
 /* H:5283-5524 inter_choose_mode */
-template <class HOOK> DEV void inter_choose(RowLds &L, MbBuf &B, MbCtx &m, HOOK noskip)
+/* sig: what the two-wave pipeline wants to hear before the decision is complete (enc_row.h NoSignals / h264e_kernels.hip SearchSignals):
+ * noskip() once the early-skip test has failed, bound(u) as soon as an upper bound u of the final inter cost is known */
+template <class SIG> DEV void inter_choose(RowLds &L, MbBuf &B, MbCtx &m, SIG sig)
 {
     int prefer[4] = { 1, 0, 0, 0 };      /* constant indices only after unrolling: stays in registers */
     const RefView &R = m.rv;
@@ -563,7 +570,7 @@ template <class HOOK> DEV void inter_choose(RowLds &L, MbBuf &B, MbCtx &m, HOOK 
             j = 1;
         }
     }
-    noskip();                   /* not an early skip: the intra candidates will be wanted */
+    sig.noskip();               /* not an early skip: the intra candidates will be wanted */
 
     STAMP(L, 3);
     m.used_cand = 1;
@@ -616,6 +623,14 @@ template <class HOOK> DEV void inter_choose(RowLds &L, MbBuf &B, MbCtx &m, HOOK 
         }
     }
     sad_best += mv_cost(m, mv_best, mv_pred16);
+    {
+        /* An upper bound of the cost this function will end with: the 16x16 search starts at sad_best and only improves it (diamond_g), the
+         * decision is the minimum over the partition types, and when the skip vector's SAD is below that minimum the cost becomes
+         * sad_skip + its vector cost (the last lines of this function), which may be larger than the minimum but not than this bound. */
+        int u = MUL_LAMBDA(1, m.lambda_q4) + sad_best;
+        if (sad_skip != 0x7FFFFFFF) u = imax(u, sad_skip + mv_cost(m, mv_skip, mv_pred16));
+        sig.bound(u);
+    }
     STAMP(L, 4);
 
     /* H:3646-3671: every partitioning is tried from the same predictor state; H:5283-5524's loop over the partition types runs as
@@ -719,20 +734,19 @@ template <class BOUND> DEV int intra4_choose(RowLds &L, MbBuf &B, const MbCtx &m
         L.i4_left[r] = B.i4_top[c] = (int8_t)mode;
         L.i4_mode[n] = (int8_t)(mode == mpred ? -1 : mode > mpred ? mode - 1 : mode);
         unsigned coded = 0;
-        if (sad > m.skip_thr_i4)
+        cost += sad;
+        if (cost >= bound()) return I4_LOST;
+        if (sad > m.skip_thr_i4) coded = i4_block_code(bin, pr, blk, 24, L.qy + n, L.qdat[0]);     /* transform, quantiser, reconstruction -> working picture */
+        else
         {
-            coded = wave_xform_quant(bin, pr, QMODE_I4, L.qy + n, (int16_t *)0, L.qdat[0]);
-            if (coded) wave_recon(pr, 16, pr, L.qy + n, 1, 0x80000000u);
-        } else
-        {
-            WAVE_FOR(l) { if (l < 16) { L.qy[n].qv[l] = 0; L.qy[n].dq[l] = 0; } }
+            WAVE_FOR(l)
+            {
+                if (l < 16) { L.qy[n].qv[l] = 0; L.qy[n].dq[l] = 0; }
+                if (l < 4) lds32_store(blk + 24*l, lds32(pr + 16*l));
+            }
             wave_sync();
         }
         nz_mask = (nz_mask << 1) | coded;
-        cost += sad;
-        if (cost >= bound()) return I4_LOST;
-        WAVE_FOR(l) { if (l < 4) lds32_store(blk + 24*l, lds32(pr + 16*l)); }
-        wave_sync();
     }
     nz_mask_out = nz_mask & 0xffff;
     return cost;

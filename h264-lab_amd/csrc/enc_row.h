@@ -59,7 +59,7 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
     L.bw.cap = (uint32_t)G.row_words;
     L.bw.buf = C.rowbits + (size_t)row*G.row_words;
     L.skip_run = 0; L.lead_skips = 0; L.coded_any = 0; L.far_reads[0] = L.far_reads[1] = 0; L.far_fail[0] = L.far_fail[1] = 0;
-    L.f_loaded = L.f_noskip = L.f_inter = L.f_decided = L.f_wdone = L.f_stop = 0;
+    L.f_noskip = L.f_bound = L.f_inter = L.f_decided = L.f_wdone = L.f_stop = 0; L.early_bound = 0;
     WAVE_FOR(l) { if (l <= H264E_MAX_SLICES) L.slice_row[l] = l <= T.nslices ? T.slice_row[l] : (int16_t)0x7fff; }
     WAVE_FOR(l)
     {
@@ -197,14 +197,15 @@ template <bool NARROW> DEV void mb_ctx_init(MbCtx &m, RowLds &L, const h264e_geo
 }
 
 /* search side.  The input macroblock, the reference window (row_prefetch) and the records of the row above (load_top) are already in
- * LDS.  noskip() is called once the
+ * LDS.  sig (inter_choose): sig.noskip() is called once the
  * early-skip test has failed (the reconstruction side may start on the intra candidates then). */
-template <bool NARROW, class HOOK> DEV void mb_search(RowLds &L, MbBuf &B, const h264e_geom_t &G, const RowTask &T, int row, int x, int row0, HOOK noskip)
+struct NoSignals { DEVM void noskip() const {} DEVM void bound(int) const {} };
+template <bool NARROW, class SIG> DEV void mb_search(RowLds &L, MbBuf &B, const h264e_geom_t &G, const RowTask &T, int row, int x, int row0, SIG sig)
 {
     MbCtx m;
     mb_ctx_init<NARROW>(m, L, G, T, row, x, row0, 0);
     STAMP(L, 1);
-    if (T.slice_type == 0) inter_choose(L, B, m, noskip);
+    if (T.slice_type == 0) inter_choose(L, B, m, sig);
     STAMP(L, 7);
     B.type = m.type; B.cost = m.cost; B.used_cand = m.used_cand; B.mv_skip_pred = m.mv_skip_pred;
     wave_sync();
@@ -216,6 +217,7 @@ struct InterIsThere
     DEVM bool ready() const { return true; }
     DEVM bool wait_noskip_or_ready() const { return true; }
     DEVM bool wait_ready() const { return true; }
+    DEVM int early_bound() const { return 0x7fffffff; }
 };
 
 /* reconstruction side, first half: the intra candidates and the final decision.  The intra candidates do not need the inter decision
@@ -239,7 +241,11 @@ template <class P> DEV bool mb_intra_decide(RowLds &L, MbBuf &B, MbCtx &m, const
         unsigned nz4 = 0;
         if (T.speed < 2 || T.slice_type != 0)
             cost4 = intra4_choose(L, B, m, [&]() -> int {
-                if (!have && pol.ready()) { have = true; bnd = imin(bnd, uni(B.cost)); }
+                if (!have)
+                {
+                    if (pol.ready()) { have = true; bnd = imin(bnd, uni(B.cost)); }
+                    else bnd = imin(bnd, pol.early_bound());         /* the search wave's upper bound of the inter cost, once it has one */
+                }
                 return bnd;
             }, nz4);
         STAMP(L, 9);
@@ -435,7 +441,7 @@ template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const
     MbBuf &B = L.mb[x & 1];
     MbCtx m;
     load_top(L, B, G, C.bottom + (size_t)(row - 1)*G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, row > row0);
-    mb_search<NARROW>(L, B, G, T, row, x, row0, []() {});
+    mb_search<NARROW>(L, B, G, T, row, x, row0, NoSignals());
     mb_ctx_init<NARROW>(m, L, G, T, row, x, row0, 1);
     mb_intra_decide(L, B, m, T, InterIsThere());
     mb_recon_write<NARROW>(L, B, m, G, C, T, row, x, row0, row1);

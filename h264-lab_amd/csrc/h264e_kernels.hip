@@ -64,6 +64,14 @@ DEV int lds_wait(const int *flag, int need, int *stop)
         __builtin_amdgcn_s_sleep(1);
     }
 }
+/* what the search wave tells the reconstruction wave while it is still searching macroblock need - 1 (enc_mb.h inter_choose) */
+struct SearchSignals
+{
+    RowLds *L;
+    int need;
+    DEVM void noskip() const { flag_set(&L->f_noskip, need); }
+    DEVM void bound(int u) const { L->early_bound = u; flag_set(&L->f_bound, need); }
+};
 /* the reconstruction wave's view of the inter decision of macroblock need - 1 (enc_row.h mb_intra_decide) */
 struct InterFromSearchWave
 {
@@ -71,6 +79,7 @@ struct InterFromSearchWave
     int need;
     DEVM bool ready() const { return uni(flag_get(&L->f_inter)) >= need; }
     DEVM bool wait_ready() const { return lds_wait(&L->f_inter, need, &L->f_stop) == 0; }
+    DEVM int early_bound() const { return uni(flag_get(&L->f_bound)) >= need ? uni(L->early_bound) : 0x7fffffff; }
     DEVM bool wait_noskip_or_ready() const
     {
         for (unsigned spins = 0;; spins++)
@@ -317,7 +326,7 @@ __global__ void __launch_bounds__(64*WAVES, WAVES == 2 ? H264E_WPE2 : H264E_WPE1
                 return;
             }
             if (WAVES == 1) row_step<NARROW>(L, G, C, RT, row, x, row0, row1);
-            else mb_search<NARROW>(L, L.mb[x & 1], G, RT, row, x, row0, [&]() { flag_set(&L.f_noskip, x + 1); });
+            else mb_search<NARROW>(L, L.mb[x & 1], G, RT, row, x, row0, SearchSignals{ &L, x + 1 });
             {
                 /* a far reference read of this macroblock waited in vain (rv_wait_rect): what it encoded is not trustworthy */
                 const int ff = uni(L.far_fail[0]) | (WAVES == 1 ? uni(L.far_fail[1]) : 0);

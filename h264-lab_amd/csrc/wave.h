@@ -118,6 +118,30 @@ template <class F> DEV void grp_eval4(F f, int out[4]) { for (int d = 0; d < 4; 
 template <class F> DEV void grp_eval8(F f, int out[8]) { for (int d = 0; d < 8; ++d) out[d] = f(d); }
 DEV void grp_count(int *p) { *p += 1; }
 
+/* ---- V16 (see the device build below): the emulation keeps the 16 lanes of a tile in an array */
+struct V16 { int v[16]; };
+#define V16_BINOP(op) DEV V16 operator op(const V16 &a, const V16 &b) { V16 r; for (int i = 0; i < 16; i++) r.v[i] = a.v[i] op b.v[i]; return r; }
+V16_BINOP(+) V16_BINOP(-) V16_BINOP(*) V16_BINOP(&) V16_BINOP(|)
+#undef V16_BINOP
+DEV V16 operator>>(const V16 &a, int s) { V16 r; for (int i = 0; i < 16; i++) r.v[i] = a.v[i] >> s; return r; }
+DEV V16 v16_splat(int s) { V16 r; for (int i = 0; i < 16; i++) r.v[i] = s; return r; }
+template <class F> DEV V16 v16_make(F f) { V16 r; for (int i = 0; i < 16; i++) r.v[i] = f(i, 0); return r; }            /* r[i] = f(i, tile) */
+template <class F> DEV V16 v16_map(const V16 &a, F f) { V16 r; for (int i = 0; i < 16; i++) r.v[i] = f(i, a.v[i]); return r; }
+template <class F> DEV V16 v16_map2(const V16 &a, const V16 &b, F f) { V16 r; for (int i = 0; i < 16; i++) r.v[i] = f(i, a.v[i], b.v[i]); return r; }
+template <class F> DEV void v16_each(const V16 &a, F f) { for (int i = 0; i < 16; i++) f(i, 0, a.v[i]); }                  /* f(i, tile, value): stores */
+template <int P0, int P1, int P2, int P3> DEV V16 v16_quadperm(const V16 &a)
+{
+    const int p[4] = { P0, P1, P2, P3 };
+    V16 r;
+    for (int i = 0; i < 16; i++) r.v[i] = a.v[(i & ~3) | p[i & 3]];
+    return r;
+}
+DEV V16 v16_xpose(const V16 &a) { V16 r; for (int i = 0; i < 16; i++) r.v[i] = a.v[(i & 3)*4 + (i >> 2)]; return r; }
+DEV V16 v16_from(const V16 &a, const V16 &idx) { V16 r; for (int i = 0; i < 16; i++) r.v[i] = a.v[idx.v[i] & 15]; return r; }   /* r[i] = a[idx[i]] */
+/* bit i of the result: lane i's value is non-zero; tiles: how many of the wave's four tiles take part (the emulation runs one) */
+DEV unsigned v16_nonzero_mask(const V16 &a) { unsigned m = 0; for (int i = 0; i < 16; i++) if (a.v[i]) m |= 1u << i; return m; }
+#define V16_TILES 1
+
 #else /* device build */
 
 #include <hip/hip_runtime.h>
@@ -237,6 +261,46 @@ template <class F> DEV void grp_eval8(F f, int out[8])
 }
 /* a statistics counter in LDS, bumped once per group */
 DEV void grp_count(int *p) { if ((LANE & 15) == 0) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+/*
+ * V16: one value per lane of a 16-lane tile (a 4x4 block: lane i = 4*row + column, or coefficient index), for the 4x4 transforms,
+ * the quantiser and the intra 4x4 reconstruction -- the data stays in registers and moves between lanes with DPP (inside the
+ * quads) and ds_bpermute (transpose) instead of going through LDS between every step.  The wavefront holds FOUR tiles (one per DPP
+ * row): kernels that work on one block (intra 4x4: a serial chain) run the same block in all four, kernels with independent blocks
+ * (mb_write) give each row its own (tile index = LANE >> 4).  Written once for both builds: the emulation (above) keeps arrays.
+ */
+struct V16 { int v; };
+#define V16_BINOP(op) DEV V16 operator op(const V16 &a, const V16 &b) { V16 r; r.v = a.v op b.v; return r; }
+V16_BINOP(+) V16_BINOP(-) V16_BINOP(*) V16_BINOP(&) V16_BINOP(|)
+#undef V16_BINOP
+DEV V16 operator>>(const V16 &a, int s) { V16 r; r.v = a.v >> s; return r; }
+DEV V16 v16_splat(int s) { V16 r; r.v = s; return r; }
+template <class F> DEV V16 v16_make(F f) { V16 r; r.v = f(LANE & 15, LANE >> 4); return r; }
+template <class F> DEV V16 v16_map(const V16 &a, F f) { V16 r; r.v = f(LANE & 15, a.v); return r; }
+template <class F> DEV V16 v16_map2(const V16 &a, const V16 &b, F f) { V16 r; r.v = f(LANE & 15, a.v, b.v); return r; }
+template <class F> DEV void v16_each(const V16 &a, F f) { f(LANE & 15, LANE >> 4, a.v); }
+template <int P0, int P1, int P2, int P3> DEV V16 v16_quadperm(const V16 &a)
+{
+    V16 r;
+    r.v = __builtin_amdgcn_update_dpp(0, a.v, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xf, 0xf, true);
+    return r;
+}
+DEV V16 v16_xpose(const V16 &a)
+{
+    V16 r;
+    r.v = __builtin_amdgcn_ds_bpermute(4*((LANE & 48) | ((LANE & 3) << 2) | ((LANE >> 2) & 3)), a.v);
+    return r;
+}
+DEV V16 v16_from(const V16 &a, const V16 &idx)
+{
+    V16 r;
+    r.v = __builtin_amdgcn_ds_bpermute(4*((LANE & 48) | (idx.v & 15)), a.v);
+    return r;
+}
+/* bits 16t .. 16t+15 of the ballot belong to tile t */
+DEV unsigned long long v16_nonzero_ballot(const V16 &a) { return __ballot(a.v != 0); }
+DEV unsigned v16_nonzero_mask(const V16 &a) { return (unsigned)(__ballot(a.v != 0) & 0xffffu); }
+#define V16_TILES 4
 #endif
 
 /* diagnostic build only (-DH264E_STAMPS): cycle stamps per pipeline phase, accumulated in LDS (never in the product) */

@@ -10,12 +10,12 @@ sys.path.insert(0, ROOT)
 os.environ["H264E_LIB"] = os.path.join(ROOT, "h264-lab_amd", "lib", "libh264e_mi355x_stamps.so")
 from __graft_entry__ import _pkg  # noqa: E402
 
-NAMES = {0: "S load input + window + records above", 1: "S setup", 2: "S inter: predictors", 3: "S inter: skip test", 4: "S inter: candidates", 5: "S inter: partition search (4 lane groups)",
+NAMES = {0: "S load input + window + records above", 1: "S setup", 2: "S inter: predictors", 3: "S inter: skip test", 4: "S inter: candidates", 5: "S inter: partition search: entry/exit", 24: "S   search: set-up per partition (predictor, range, start SAD)", 25: "S   search: full-pel scan", 26: "S   search: sub-pel", 27: "S   search: bookkeeping",
          7: "S inter: rest", 13: "S WAIT row above / reference frame (poll+acquire)", 23: "S wait: hand-off buffer free (R wave 2 MBs behind)", 6: "S wait: decision of x-1 (R wave)",
          15: "R wait: search wave's skip test", 8: "R intra 16x16", 9: "R intra 4x4", 16: "R wait: inter decision", 10: "R merge + contexts + chroma prediction",
          11: "R mb_write (xform/quant/CAVLC/recon)", 12: "R ctx save + deblock + stores", 14: "publish / signal"}
-ORDER = [13, 23, 0, 6, 1, 2, 3, 4, 5, 7, 15, 8, 9, 16, 10, 11, 12, 14]
-SEARCH_SIDE = {13, 23, 0, 6, 1, 2, 3, 4, 5, 7}
+ORDER = [13, 23, 0, 6, 1, 2, 3, 4, 5, 24, 25, 26, 27, 7, 15, 8, 9, 16, 10, 11, 12, 14]
+SEARCH_SIDE = {13, 23, 0, 6, 1, 2, 3, 4, 5, 24, 25, 26, 27, 7}
 
 
 def main():
@@ -42,6 +42,9 @@ def main():
     s_tot = sum(t[i] for i in ORDER if i in SEARCH_SIDE)
     print("%-58s %12.0f" % ("total search side", s_tot / nmb))
     print("%-58s %12.0f" % ("total reconstruction side", (tot - s_tot) / nmb))
+    if t[24]:
+        print("inside the partition search, cycles/MB: set-up per partition (predictor, range, start SAD) %.0f | full-pel scan %.0f | sub-pel %.0f | bookkeeping %.0f" %
+              (t[24] / nmb, t[25] / nmb, t[26] / nmb, t[27] / nmb))
     if t[18]:
         print("partition searches (serial steps of the lane groups)/MB %.2f  scan iterations/step %.1f  SAD batches/step %.2f" % (t[18] / nmb, t[19] / t[18], t[17] / t[18]))
     if t[30]:
