@@ -47,7 +47,7 @@ class ClipParam(C.Structure):
 class ClipStats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("upload_ms", "encode_ms", "readback_ms", "assemble_ms", "mb_kernel_ms", "splice_kernel_ms")] + \
                [(n, C.c_int) for n in ("kernel_launches", "chains", "rounds", "reencoded_gops")] + \
-               [("mv_clusters_out", C.c_int32 * 2), ("next_idr_pic_id_state", C.c_int), ("first_frame", C.c_int), ("frames", C.c_int)]
+               [("mv_clusters_out", C.c_int32 * 2), ("next_idr_pic_id_state", C.c_int), ("first_frame", C.c_int), ("frames", C.c_int), ("spin_relaunches", C.c_int)]
 
 
 def lib_path():
@@ -188,6 +188,30 @@ class ClipEncoder:
         if self.L.H264E_clip_encode(self.c, out.ctypes.data, cap, C.byref(nb), sizes, int(profile), C.byref(st)):
             raise _err(self.L, "H264E_clip_encode")
         return out[: nb.value].tobytes(), list(sizes)[: st.frames], st
+
+    @staticmethod
+    def encode_multi(encoders):
+        """Encode several clips of one picture size on one device AT THE SAME TIME (H264E_clip_encode_multi: one host thread per clip,
+        the clips' launches merged into one grid per round).  Returns a list of (bytes, sizes, stats), one per encoder."""
+        n = len(encoders)
+        L = encoders[0].L
+        caps = [e.w * e.h * 3 // 2 * e.n + (1 << 20) for e in encoders]
+        outs = [np.empty(c, np.uint8) for c in caps]
+        sizes = [(C.c_int * e.n)() for e in encoders]
+        sts = (ClipStats * n)()
+        nb = (C.c_size_t * n)()
+        for e in encoders:
+            L.H264E_clip_rewind(e.c)
+        L.H264E_clip_encode_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                              C.POINTER(C.POINTER(C.c_int)), C.POINTER(ClipStats)]
+        L.H264E_clip_encode_multi.restype = C.c_int
+        clips = (C.c_void_p * n)(*[e.c for e in encoders])
+        outp = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        capa = (C.c_size_t * n)(*caps)
+        fb = (C.POINTER(C.c_int) * n)(*[C.cast(s, C.POINTER(C.c_int)) for s in sizes])
+        if L.H264E_clip_encode_multi(clips, n, outp, capa, nb, fb, sts):
+            raise _err(L, "H264E_clip_encode_multi")
+        return [(outs[i][: nb[i]].tobytes(), list(sizes[i])[: sts[i].frames], sts[i]) for i in range(n)]
 
     def revalidate(self, exact_in):
         """(restart_frame or -1, restart_state, end_state) for the exact mv_clusters state in front of this shard"""

@@ -159,7 +159,10 @@ typedef struct
     int qp;
     int speed;
     int no_deblock;
-    int chain;                          /* which chain's row/record/result buffers this job uses */
+    int chain;                          /* which chain's row/record/result buffers this job uses ... */
+    const h264e_chain_dev_t *chain_desc; /* ... = its descriptor in device memory (the jobs of one launch may belong to different pools: launch groups) */
+    int *errflag;                       /* device word of the job's pool: set when a bounded wait expires */
+    int *stepflags;                     /* device [2]: {clusters_moved, overflow} of this job (plain mode) */
     const uint8_t *ref[3];              /* reference picture (coded size, stride = width); unused for I slices */
     uint8_t *dec[3];                    /* picture being built */
     int arena_reset;                    /* the result goes to the start of the chain's arena (one result per chain slot) */

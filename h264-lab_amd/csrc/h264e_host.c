@@ -1103,7 +1103,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
     long long far_reads = 0;
     uint16_t qdat_i[2][42], qdat_p[2][42];
     size_t pos = 0;
-    int rc = -1, i, full = 0, qp = c->rc_qp;
+    int rc = -1, i, full = 0, qp = c->rc_qp, spin_retries = 0;
     H264E_clip_stats_t stats;
     double t0;
     memset(&stats, 0, sizeof(stats));
@@ -1207,7 +1207,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
         c->have_after = 0;
         const double t_submit = now_ms();
         double t_first = 0, t_last = 0;
-        int rc_miss = 0, take = -1, moved_from = -1, moved_to = -1;
+        int rc_miss = 0, take = -1, moved_from = -1, moved_to = -1, relaunch = 0;
         if (h264e_hip_submit(c->pool, tasks)) goto done;
 
         /* consume the frames in stream order while the launch is still running */
@@ -1250,7 +1250,17 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             if (dn != 1)
             {
                 if (dn < 0) goto done;
-                (void)h264e_hip_sync(c->pool);                          /* reports a kernel-side failure, if any */
+                /* The frame did not complete and nobody asked it to stop.  When the kernel reports that a bounded wait expired -- workgroups
+                 * starved of wave slots, e.g. by another process' launch on the same device -- nothing wrong was returned: every frame
+                 * accepted so far stands, and the unfinished ones are simply launched again (a fresh launch in this process).  Anything
+                 * else, and a wait that keeps expiring without a single frame getting through, is an error. */
+                if (h264e_hip_sync(c->pool) && strstr(h264e_hip_last_error(), "bounded spin expired") && spin_retries < 3)
+                {
+                    spin_retries++;
+                    stats.spin_relaunches++;
+                    relaunch = 1;
+                    break;
+                }
                 if (!g_host_err[0] && !h264e_hip_last_error()[0]) snprintf(g_host_err, sizeof(g_host_err), "frame %d did not complete", f);
                 goto done;
             }
@@ -1331,7 +1341,9 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             }
             if (take >= 0) i = F - 1;           /* the chain ends here: one more round, for the leaf */
         }
-        if (h264e_hip_sync(c->pool)) goto done;         /* the launch has drained (immediately after an abort) */
+        if (relaunch) { (void)h264e_hip_stream_abort(c->pool); (void)h264e_hip_sync(c->pool); }       /* (the failure was reported above; the launch is over) */
+        else if (h264e_hip_sync(c->pool)) goto done;    /* the launch has drained (immediately after an abort) */
+        if (nvalid) spin_retries = 0;
         if (moved_from >= 0 && h264e_hip_stream_copy_picture(c->pool, moved_from, moved_to)) goto done;
         stats.encode_ms += now_ms() - t_submit;
         if (c->ssd_out && nvalid)
@@ -1379,5 +1391,63 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
 done:
     if (rc) h264e_hip_release(c->pool);         /* a failure between submit and sync: give the device's launch lock back */
     if (st) *st = stats;
+    return rc;
+}
+
+
+/* ------------------------------------------------------------------ several clips of one picture size on ONE device at once */
+
+typedef struct
+{
+    H264E_clip_t *clip; h264e_hip_group_t *group;
+    uint8_t *out; size_t cap; size_t *out_bytes; int *frame_bytes; H264E_clip_stats_t *st;
+    int rc; char err[256];
+} multi_arg_t;
+
+static void *multi_thread(void *p)
+{
+    multi_arg_t *a = (multi_arg_t *)p;
+    a->rc = H264E_clip_encode(a->clip, a->out, a->cap, a->out_bytes, a->frame_bytes, 0, a->st);
+    if (a->rc) snprintf(a->err, sizeof(a->err), "%s", H264E_last_error());
+    h264e_hip_group_leave(a->group, a->clip->pool);     /* the others no longer wait for this one's launches */
+    return NULL;
+}
+
+/*
+ * A single-slice stream spends most of a pass in pipeline drains and refills (one per mis-speculated mv_clusters state);
+ * independent streams fill each other's gaps when their frames share ONE launch (include/h264e_hip.h launch groups): every clip is
+ * encoded by its own host thread exactly like H264E_clip_encode does, the device layer merges the threads' launches round by round.
+ * Same bytes per clip as H264E_clip_encode.
+ */
+int H264E_clip_encode_multi(H264E_clip_t **clips, int nclips, uint8_t **out, const size_t *cap, size_t *out_bytes, int **frame_bytes, H264E_clip_stats_t *stats)
+{
+    h264e_hip_group_t *g = NULL;
+    multi_arg_t *a;
+    pthread_t *th;
+    int i, rc = 0, started = 0;
+    g_host_err[0] = 0;
+    if (!clips || nclips <= 0 || !out || !cap || !out_bytes) { snprintf(g_host_err, sizeof(g_host_err), "clip_encode_multi: bad argument"); return -1; }
+    if (nclips == 1) return H264E_clip_encode(clips[0], out[0], cap[0], &out_bytes[0], frame_bytes ? frame_bytes[0] : NULL, 0, stats);
+    a = (multi_arg_t *)calloc((size_t)nclips, sizeof(*a));
+    th = (pthread_t *)calloc((size_t)nclips, sizeof(*th));
+    if (!a || !th || h264e_hip_group_create(&g, clips[0] ? clips[0]->par.device : 0)) { free(a); free(th); if (!g_host_err[0]) snprintf(g_host_err, sizeof(g_host_err), "clip_encode_multi: %s", h264e_hip_last_error()); return -1; }
+    for (i = 0; i < nclips && !rc; i++)
+        if (!clips[i] || h264e_hip_group_join(g, clips[i]->pool)) { snprintf(g_host_err, sizeof(g_host_err), "clip_encode_multi: clip %d cannot join (%s)", i, h264e_hip_last_error()); rc = -1; }
+    for (i = 0; i < nclips && !rc; i++)
+    {
+        a[i].clip = clips[i]; a[i].group = g; a[i].out = out[i]; a[i].cap = cap[i]; a[i].out_bytes = &out_bytes[i];
+        a[i].frame_bytes = frame_bytes ? frame_bytes[i] : NULL; a[i].st = stats ? &stats[i] : NULL;
+        if (pthread_create(&th[i], NULL, multi_thread, &a[i])) { snprintf(g_host_err, sizeof(g_host_err), "clip_encode_multi: cannot start a thread"); rc = -1; break; }
+        started++;
+    }
+    /* a clip whose thread never started must not be waited for by the others */
+    for (i = started; i < nclips; i++) if (clips[i]) h264e_hip_group_leave(g, clips[i]->pool);
+    for (i = 0; i < started; i++)
+    {
+        pthread_join(th[i], NULL);
+        if (a[i].rc && !rc) { rc = a[i].rc; snprintf(g_host_err, sizeof(g_host_err), "clip %d: %s", i, a[i].err); }
+    }
+    h264e_hip_group_destroy(g);
+    free(a); free(th);
     return rc;
 }

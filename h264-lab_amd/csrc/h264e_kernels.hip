@@ -113,8 +113,7 @@ struct InterFromSearchWave
 #define H264E_WPE1 2
 #endif
 template <bool NARROW, int WAVES>
-__global__ void __launch_bounds__(64*WAVES, WAVES == 2 ? H264E_WPE2 : H264E_WPE1) h264e_mb_kernel(h264e_geom_t G, const h264e_chain_dev_t *chains,
-                                                               const h264e_frame_task_t *tasks, const uint32_t *order, int *errflag, int *stepflags)
+__global__ void __launch_bounds__(64*WAVES, WAVES == 2 ? H264E_WPE2 : H264E_WPE1) h264e_mb_kernel(h264e_geom_t G, const h264e_frame_task_t *tasks, const uint32_t *order)
 {
     __shared__ RowLds L;
     const int wv = WAVES == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;     /* which wavefront of the workgroup */
@@ -130,7 +129,8 @@ __global__ void __launch_bounds__(64*WAVES, WAVES == 2 ? H264E_WPE2 : H264E_WPE1
     const int job = (int)(jr >> 16), row = (int)(jr & 0xffffu);
     const h264e_frame_task_t &T = tasks[job];
     if (!T.active) return;
-    const ChainG C = chain_view(chains[T.chain]);
+    const ChainG C = chain_view(*T.chain_desc);
+    GLOBAL_AS int *errflag = (GLOBAL_AS int *)uniptr(T.errflag);
 
     if (row == G.nmby)
     {
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(64*WAVES, WAVES == 2 ? H264E_WPE2 : H264E_WPE1
                 return;
             }
         }
-        finalize_frame(G, C, T, (GLOBAL_AS int *)stepflags + 2*job);
+        finalize_frame(G, C, T, (GLOBAL_AS int *)T.stepflags);
         if (hd)
         {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
@@ -693,6 +693,9 @@ static pthread_once_t g_device_lock_once = PTHREAD_ONCE_INIT;
 static void device_locks_init(void) { for (int i = 0; i < H264E_MAX_DEVICES; i++) pthread_mutex_init(&g_device_lock[i], 0); }
 #endif
 
+struct h264e_hip_group;
+typedef struct h264e_hip_group h264e_hip_group_t;
+
 struct h264e_hip_pool
 {
     int device, nchains, frames_resident, slots;
@@ -728,15 +731,36 @@ struct h264e_hip_pool
     int *ref_sel;                        /* per chain */
     int ring_pos, pending;
     int profile, prof_launches;
+    struct h264e_hip_group *group;       /* launch group this pool's submits go through, or NULL */
+    int group_round;                     /* the group round of its last submit */
     int waves;                           /* wavefronts per macroblock row forced by H264E_WAVES (1 or 2); 0 = chosen per launch (h264e_hip_submit) */
     int test_upload_fail_at, async_uploads;     /* fault injection (H264E_TEST_KNOBS): the n-th asynchronous upload of this pool fails */
     double prof_mb_ms, prof_splice_ms;
 #ifndef H264E_EMU
     hipStream_t stream;
     hipStream_t copy_stream;             /* uploads that overlap with kernels on `stream` */
-    hipEvent_t ev_t0, ev_t1;
+    hipEvent_t ev_t0, ev_t1, ev_prep;
     hipEvent_t ev[TASK_RING][3];         /* per pending submit: before / between / after the two kernels */
     int ev_pending;
+#endif
+};
+
+/* launch groups (see h264e_hip_group_create below) */
+#define H264E_GROUP_MAX 8
+struct h264e_hip_group
+{
+    int device, nmembers, arrived, round, failed;
+    h264e_hip_pool_t *member[H264E_GROUP_MAX];
+    /* what each member wants launched this round */
+    h264e_frame_task_t *pend_tasks[H264E_GROUP_MAX];
+    int pend_jobs[H264E_GROUP_MAX], pend_narrow[H264E_GROUP_MAX], pend_waves[H264E_GROUP_MAX], pend[H264E_GROUP_MAX];
+#ifndef H264E_EMU
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    hipStream_t stream;
+    hipEvent_t ev_done, ev_t0, ev_t1;
+    h264e_frame_task_t *tasks_dev; size_t tasks_cap;
+    uint32_t *order_dev; size_t order_cap;
 #endif
 };
 
@@ -785,7 +809,7 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
     if (p->stream)
     {
         for (int i = 0; i < TASK_RING; i++) for (int k = 0; k < 3; k++) (void)hipEventDestroy(p->ev[i][k]);
-        (void)hipEventDestroy(p->ev_t0); (void)hipEventDestroy(p->ev_t1);
+        (void)hipEventDestroy(p->ev_t0); (void)hipEventDestroy(p->ev_t1); (void)hipEventDestroy(p->ev_prep);
         (void)hipStreamDestroy(p->stream);
         if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     }
@@ -893,7 +917,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     if (hipSetDevice(device) != hipSuccess) { free(p); FAIL("hipSetDevice(%d) failed", device); }
     if (hipStreamCreate(&p->stream) != hipSuccess || hipStreamCreate(&p->copy_stream) != hipSuccess) { free(p); FAIL("hipStreamCreate failed"); }
     for (int i = 0; i < TASK_RING; i++) for (int k = 0; k < 3; k++) (void)hipEventCreate(&p->ev[i][k]);
-    (void)hipEventCreate(&p->ev_t0); (void)hipEventCreate(&p->ev_t1);
+    (void)hipEventCreate(&p->ev_t0); (void)hipEventCreate(&p->ev_t1); (void)hipEventCreate(&p->ev_prep);
 #endif
     p->chains_host = (h264e_chain_dev_t *)calloc((size_t)nchains, sizeof(h264e_chain_dev_t));
     p->clu_dev = (int32_t **)calloc((size_t)nchains, sizeof(int32_t *));
@@ -1164,6 +1188,17 @@ extern "C" int h264e_hip_sync(h264e_hip_pool_t *p)
     if (!p) FAIL("sync: null pool");
 #ifndef H264E_EMU
     HIPCHK(hipSetDevice(p->device));
+    if (p->group)
+    {
+        /* the merged launch of the round this pool submitted in (all members' jobs) */
+        const hipError_t eg = hipEventSynchronize(p->group->ev_done);
+        if (eg != hipSuccess) FAIL("group launch: %s", hipGetErrorString(eg));
+        if (p->profile && p->group->nmembers && p->group->member[0] == p)
+        {
+            float a = 0;
+            if (hipEventElapsedTime(&a, p->group->ev_t0, p->group->ev_t1) == hipSuccess) { p->prof_mb_ms += a; p->prof_launches++; }
+        }
+    }
     {
         const hipError_t es = hipStreamSynchronize(p->stream);
         device_release(p);              /* drained (or lost): the next launch on this device may go */
@@ -1199,6 +1234,221 @@ extern "C" void h264e_hip_release(h264e_hip_pool_t *p)
     if (p->stream) (void)hipStreamSynchronize(p->stream);
 #endif
     device_release(p);
+}
+
+#ifndef H264E_EMU
+static void launch_mb_kernel(const h264e_geom_t &G, int narrow, int waves, unsigned nblocks, const h264e_frame_task_t *td, const uint32_t *od, hipStream_t st)
+{
+    const dim3 grid(nblocks);
+    if (waves == 2)
+    {
+        if (narrow) hipLaunchKernelGGL((h264e_mb_kernel<true, 2>), grid, dim3(128), 0, st, G, td, od);
+        else hipLaunchKernelGGL((h264e_mb_kernel<false, 2>), grid, dim3(128), 0, st, G, td, od);
+    } else
+    {
+        if (narrow) hipLaunchKernelGGL((h264e_mb_kernel<true, 1>), grid, dim3(64), 0, st, G, td, od);
+        else hipLaunchKernelGGL((h264e_mb_kernel<false, 1>), grid, dim3(64), 0, st, G, td, od);
+    }
+}
+#endif
+
+/* ------------------------------------------------------------------ launch groups: several streams in ONE launch
+ *
+ * A single-slice stream is latency bound: after every mis-speculated mv_clusters state its pipeline drains and refills, and the chip
+ * idles meanwhile.  Independent streams of the same picture size can fill each other's gaps -- but not as separate launches (see
+ * g_device_lock: two persistent launches side by side can starve each other).  A group merges the launches of its member pools into ONE
+ * grid: every member submits as usual (h264e_hip_submit blocks until all members that are still encoding have submitted or left), the
+ * last one to arrive concatenates the jobs, interleaves the members' dispatch orders by start step -- so the streams advance in lock step
+ * and every workgroup still only waits for workgroups in front of it -- and launches once.  Each job keeps its own pool's buffers, abort
+ * word, error word and host mirrors (h264e_frame_task_t), so one stream's abort stops only its own jobs; h264e_hip_sync of a member
+ * returns when the merged launch has drained.  Members are encoded by different host threads (H264E_clip_encode_multi).
+ */
+extern "C" int h264e_hip_group_create(h264e_hip_group_t **out, int device)
+{
+    if (!out) FAIL("group_create: null argument");
+    h264e_hip_group_t *g = (h264e_hip_group_t *)calloc(1, sizeof(*g));
+    if (!g) FAIL("out of host memory");
+    g->device = device;
+#ifndef H264E_EMU
+    pthread_mutex_init(&g->mu, 0); pthread_cond_init(&g->cv, 0);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&g->stream) != hipSuccess) { free(g); FAIL("group_create: no stream on device %d", device); }
+    (void)hipEventCreate(&g->ev_done); (void)hipEventCreate(&g->ev_t0); (void)hipEventCreate(&g->ev_t1);
+#endif
+    *out = g;
+    return 0;
+}
+
+#ifndef H264E_EMU
+/* all members that are still in the group have submitted: merge and launch (g->mu held).  Members whose launches differ in kernel
+ * variant (window geometry, waves per row) go in separate launches, one after the other. */
+static int group_launch_locked(h264e_hip_group_t *g)
+{
+    int rc = 0;
+    if (hipSetDevice(g->device) != hipSuccess) rc = -1;
+    for (int variant = 0; variant < 4 && !rc; variant++)
+    {
+        const int narrow = variant & 1, waves = 1 + (variant >> 1);
+        int idx[H264E_GROUP_MAX], n = 0, jobs = 0;
+        for (int k = 0; k < g->nmembers; k++)
+            if (g->pend[k] && g->pend_narrow[k] == narrow && g->pend_waves[k] == waves) { idx[n++] = k; jobs += g->pend_jobs[k]; }
+        if (!n) continue;
+        const h264e_geom_t &G = g->member[idx[0]]->G;
+        const int rows = G.nmby + 1, lag = narrow ? H264E_NARROW_FRAME_LAG : H264E_FRAME_LAG;
+        const size_t total = (size_t)jobs*rows;
+        if (jobs >= 65536) { snprintf(g_err, sizeof(g_err), "group launch: too many jobs"); rc = -1; break; }
+        if ((size_t)jobs > g->tasks_cap)
+        {
+            if (g->tasks_dev) (void)hipFree(g->tasks_dev);
+            g->tasks_cap = (size_t)jobs + 64;
+            if (hipMalloc((void **)&g->tasks_dev, sizeof(h264e_frame_task_t)*g->tasks_cap) != hipSuccess) { g->tasks_dev = 0; g->tasks_cap = 0; snprintf(g_err, sizeof(g_err), "group launch: device allocation failed"); rc = -1; break; }
+        }
+        if (total > g->order_cap)
+        {
+            if (g->order_dev) (void)hipFree(g->order_dev);
+            g->order_cap = total + 4096;
+            if (hipMalloc((void **)&g->order_dev, sizeof(uint32_t)*g->order_cap) != hipSuccess) { g->order_dev = 0; g->order_cap = 0; snprintf(g_err, sizeof(g_err), "group launch: device allocation failed"); rc = -1; break; }
+        }
+        h264e_frame_task_t *th = (h264e_frame_task_t *)malloc(sizeof(h264e_frame_task_t)*(size_t)jobs);
+        uint32_t *oh = (uint32_t *)malloc(sizeof(uint32_t)*total);
+        if (!th || !oh) { free(th); free(oh); snprintf(g_err, sizeof(g_err), "out of host memory"); rc = -1; break; }
+        /* jobs member after member; dispatch order by start step lag*job + 2*row (a counting sort over all members: ties go member by
+         * member, so the streams are interleaved frame by frame) */
+        int base[H264E_GROUP_MAX], maxjobs = 0;
+        for (int i = 0, b = 0; i < n; i++)
+        {
+            base[i] = b;
+            memcpy(th + b, g->pend_tasks[idx[i]], sizeof(h264e_frame_task_t)*(size_t)g->pend_jobs[idx[i]]);
+            b += g->pend_jobs[idx[i]];
+            if (g->pend_jobs[idx[i]] > maxjobs) maxjobs = g->pend_jobs[idx[i]];
+        }
+        const int maxkey = lag*(maxjobs - 1) + 2*(rows - 1);
+        int *start = (int *)calloc((size_t)maxkey + 2, sizeof(int));
+        if (!start) { free(th); free(oh); snprintf(g_err, sizeof(g_err), "out of host memory"); rc = -1; break; }
+        for (int i = 0; i < n; i++) for (int j = 0; j < g->pend_jobs[idx[i]]; j++) for (int r = 0; r < rows; r++) start[lag*j + 2*r + 1]++;
+        for (int k = 0; k <= maxkey; k++) start[k + 1] += start[k];
+        for (int j = 0; j < maxjobs; j++)
+            for (int i = 0; i < n; i++)
+                if (j < g->pend_jobs[idx[i]])
+                    for (int r = 0; r < rows; r++) oh[start[lag*j + 2*r]++] = ((uint32_t)(base[i] + j) << 16) | (uint32_t)r;
+        free(start);
+        /* the members prepared their slots (progress counters, ...) on their own streams: the launch waits for all of that */
+        for (int i = 0; i < n && !rc; i++)
+        {
+            h264e_hip_pool_t *p = g->member[idx[i]];
+            if (hipEventRecord(p->ev_prep, p->stream) != hipSuccess || hipStreamWaitEvent(g->stream, p->ev_prep, 0) != hipSuccess) rc = -1;
+        }
+        if (!rc && (hipMemcpyAsync(g->tasks_dev, th, sizeof(h264e_frame_task_t)*(size_t)jobs, hipMemcpyHostToDevice, g->stream) != hipSuccess ||
+                    hipMemcpyAsync(g->order_dev, oh, sizeof(uint32_t)*total, hipMemcpyHostToDevice, g->stream) != hipSuccess)) rc = -1;
+        free(th); free(oh);            /* pageable sources: staged before the calls return */
+        if (!rc)
+        {
+            (void)hipEventRecord(g->ev_t0, g->stream);
+            launch_mb_kernel(G, narrow, waves, (unsigned)total, g->tasks_dev, g->order_dev, g->stream);
+            (void)hipEventRecord(g->ev_t1, g->stream);
+            if (hipGetLastError() != hipSuccess) rc = -1;
+        }
+        if (rc && !g_err[0]) snprintf(g_err, sizeof(g_err), "group launch failed");
+    }
+    if (hipEventRecord(g->ev_done, g->stream) != hipSuccess) rc = -1;
+    for (int k = 0; k < g->nmembers; k++) { free(g->pend_tasks[k]); g->pend_tasks[k] = 0; g->pend[k] = 0; }
+    g->arrived = 0;
+    g->failed = rc;
+    g->round++;
+    pthread_cond_broadcast(&g->cv);
+    return rc;
+}
+
+/* a member's launch: hand it to the group and wait until the merged launch is on its way */
+static int group_submit(h264e_hip_pool_t *p, const h264e_frame_task_t *host, int njobs, int narrow, int waves)
+{
+    h264e_hip_group_t *g = p->group;
+    int rc = 0, k;
+    pthread_mutex_lock(&g->mu);
+    for (k = 0; k < g->nmembers && g->member[k] != p; k++) ;
+    if (k == g->nmembers) { pthread_mutex_unlock(&g->mu); FAIL("group_submit: not a member"); }
+    g->pend_tasks[k] = (h264e_frame_task_t *)malloc(sizeof(h264e_frame_task_t)*(size_t)njobs);
+    if (!g->pend_tasks[k]) { pthread_mutex_unlock(&g->mu); FAIL("out of host memory"); }
+    memcpy(g->pend_tasks[k], host, sizeof(h264e_frame_task_t)*(size_t)njobs);
+    g->pend_jobs[k] = njobs; g->pend_narrow[k] = narrow; g->pend_waves[k] = waves; g->pend[k] = 1;
+    p->group_round = g->round;
+    g->arrived++;
+    if (g->arrived == g->nmembers) rc = group_launch_locked(g);
+    else
+    {
+        const int r = g->round;
+        while (g->round == r) pthread_cond_wait(&g->cv, &g->mu);
+        rc = g->failed;
+    }
+    pthread_mutex_unlock(&g->mu);
+    if (rc && !g_err[0]) snprintf(g_err, sizeof(g_err), "group launch failed");
+    return rc;
+}
+#endif
+
+extern "C" int h264e_hip_group_join(h264e_hip_group_t *g, h264e_hip_pool_t *p)
+{
+    if (!g || !p || p->group) FAIL("group_join: bad argument");
+#ifndef H264E_EMU
+    pthread_mutex_lock(&g->mu);
+    int bad = g->nmembers >= H264E_GROUP_MAX || p->device != g->device || g->arrived;
+    if (!bad && g->nmembers)
+    {
+        const h264e_geom_t &A = g->member[0]->G, &B = p->G;
+        bad = A.width != B.width || A.height != B.height || A.row_words != B.row_words || A.spin_limit != B.spin_limit;
+    }
+    if (!bad) { g->member[g->nmembers++] = p; p->group = g; }
+    pthread_mutex_unlock(&g->mu);
+    if (bad) FAIL("group_join: the group is full, busy, on another device or holds another picture size");
+#else
+    p->group = g; g->member[g->nmembers++] = p;     /* the emulation runs every submit by itself, at once */
+#endif
+    return 0;
+}
+
+extern "C" void h264e_hip_group_leave(h264e_hip_group_t *g, h264e_hip_pool_t *p)
+{
+    if (!g || !p || p->group != g) return;
+#ifndef H264E_EMU
+    pthread_mutex_lock(&g->mu);
+    int k;
+    for (k = 0; k < g->nmembers && g->member[k] != p; k++) ;
+    if (k < g->nmembers)
+    {
+        if (g->pend[k]) { free(g->pend_tasks[k]); g->arrived--; }
+        for (; k + 1 < g->nmembers; k++)
+        {
+            g->member[k] = g->member[k + 1]; g->pend_tasks[k] = g->pend_tasks[k + 1]; g->pend_jobs[k] = g->pend_jobs[k + 1];
+            g->pend_narrow[k] = g->pend_narrow[k + 1]; g->pend_waves[k] = g->pend_waves[k + 1]; g->pend[k] = g->pend[k + 1];
+        }
+        g->nmembers--;
+        g->pend_tasks[g->nmembers] = 0; g->pend[g->nmembers] = 0;
+        /* the others may have been waiting for this member only */
+        if (g->nmembers && g->arrived == g->nmembers) (void)group_launch_locked(g);
+    }
+    p->group = 0;
+    pthread_mutex_unlock(&g->mu);
+#else
+    for (int k = 0; k < g->nmembers; k++) if (g->member[k] == p) { g->member[k] = g->member[--g->nmembers]; break; }
+    p->group = 0;
+#endif
+}
+
+extern "C" void h264e_hip_group_destroy(h264e_hip_group_t *g)
+{
+    if (!g) return;
+#ifndef H264E_EMU
+    (void)hipSetDevice(g->device);
+    (void)hipStreamSynchronize(g->stream);
+    for (int k = 0; k < g->nmembers; k++) { g->member[k]->group = 0; free(g->pend_tasks[k]); }
+    if (g->tasks_dev) (void)hipFree(g->tasks_dev);
+    if (g->order_dev) (void)hipFree(g->order_dev);
+    (void)hipEventDestroy(g->ev_done); (void)hipEventDestroy(g->ev_t0); (void)hipEventDestroy(g->ev_t1);
+    (void)hipStreamDestroy(g->stream);
+    pthread_mutex_destroy(&g->mu); pthread_cond_destroy(&g->cv);
+#else
+    for (int k = 0; k < g->nmembers; k++) g->member[k]->group = 0;
+#endif
+    free(g);
 }
 
 extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tasks)
@@ -1286,6 +1536,9 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
                 p->slot_launch[c] = launch_id;
             }
         }
+        d.chain_desc = p->chains_dev + d.chain;
+        d.errflag = p->errflag;
+        d.stepflags = p->stepflags + 2*c;
         d.frame_slot = t.frame_slot;
         d.first_row = (t.stream_mode && t.first_row > 0 && t.first_row < G.nmby) ? t.first_row : 0;
         d.narrow = t.stream_mode && t.narrow_window;
@@ -1324,7 +1577,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         if (d.walk_on_device) p->traj_cur[t.slot] ^= 1;         /* this launch's walk writes the other buffer: it is the latest from now on */
     }
     if (!any) { free(host); return 0; }
-    device_acquire(p);                  /* one launch at a time per device (see g_device_lock) */
+    if (!p->group) device_acquire(p);   /* one launch at a time per device (see g_device_lock); a launch group owns the device as a whole (h264e_hip_group_join) */
     if (any_narrow && any_wide) { free(host); FAIL("submit: the jobs of one launch must agree on narrow_window"); }
     h264e_frame_task_t *slot = p->tasks_dev + (size_t)p->ring_pos*p->nchains;
     p->ring_pos = (p->ring_pos + 1) % TASK_RING;
@@ -1407,8 +1660,20 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             e = hipMemcpyAsync(p->chains_host[host[c].chain].progress, done, sizeof(int)*(size_t)host[c].first_row, hipMemcpyHostToDevice, p->stream);
             free(done);         /* pageable source: staged before the call returns */
         }
+    if (e != hipSuccess) { free(host); FAIL("progress reset: %s", hipGetErrorString(e)); }
+    /* wavefronts per macroblock row: two (search | reconstruction pipeline) halve the macroblock latency for twice the wave slots --
+     * the better trade wherever a launch is latency bound (single-slice streams: mis-speculation events; rate control and the
+     * frame-at-a-time API: a few frames per launch) and still level for multi-slice streams; an all-intra launch has nothing to
+     * search and no events: one wave per row, twice the rows in flight (22.4 vs 18.3 M MB/s at 1080p) */
+    const int waves = p->waves ? p->waves : all_intra ? 1 : 2;
+    if (p->group)
+    {
+        /* member of a launch group: the launch is merged with the other members' (group_launch_locked) */
+        const int grc = group_submit(p, host, njobs, any_narrow, waves);
+        free(host);
+        return grc;
+    }
     free(host);
-    if (e != hipSuccess) FAIL("progress reset: %s", hipGetErrorString(e));
     /* the dispatch order for this launch's shape (jobs up to the last active one; window geometry) */
     if (njobs != p->order_jobs || any_narrow != p->order_narrow)
     {
@@ -1418,26 +1683,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     }
     const int pe = p->ev_pending;
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][0], p->stream));
-    {
-        const dim3 grid((unsigned)(njobs*(G.nmby + 1)));
-        const h264e_chain_dev_t *cd = p->chains_dev;
-        const h264e_frame_task_t *td = slot;
-        const uint32_t *od = p->order;
-        /* wavefronts per macroblock row: two (search | reconstruction pipeline) halve the macroblock latency for twice the wave slots --
-         * the better trade wherever a launch is latency bound (single-slice streams: mis-speculation events; rate control and the
-         * frame-at-a-time API: a few frames per launch) and still level for multi-slice streams; an all-intra launch has nothing to
-         * search and no events: one wave per row, twice the rows in flight (19.3 vs 16.1 M MB/s at 1080p) */
-        const int waves = p->waves ? p->waves : all_intra ? 1 : 2;
-        if (waves == 2)
-        {
-            if (any_narrow) hipLaunchKernelGGL((h264e_mb_kernel<true, 2>), grid, dim3(128), 0, p->stream, G, cd, td, od, p->errflag, p->stepflags);
-            else hipLaunchKernelGGL((h264e_mb_kernel<false, 2>), grid, dim3(128), 0, p->stream, G, cd, td, od, p->errflag, p->stepflags);
-        } else
-        {
-            if (any_narrow) hipLaunchKernelGGL((h264e_mb_kernel<true, 1>), grid, dim3(64), 0, p->stream, G, cd, td, od, p->errflag, p->stepflags);
-            else hipLaunchKernelGGL((h264e_mb_kernel<false, 1>), grid, dim3(64), 0, p->stream, G, cd, td, od, p->errflag, p->stepflags);
-        }
-    }
+    launch_mb_kernel(G, any_narrow, waves, (unsigned)(njobs*(G.nmby + 1)), slot, p->order, p->stream);
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][1], p->stream));
     HIPCHK(hipGetLastError());
     if (p->profile)
@@ -1572,6 +1818,7 @@ extern "C" int h264e_hip_busy(h264e_hip_pool_t *p)
 #else
     if (!p) return 0;
     (void)hipSetDevice(p->device);
+    if (p->group && hipEventQuery(p->group->ev_done) == hipErrorNotReady) return 1;
     return hipStreamQuery(p->stream) == hipErrorNotReady;
 #endif
 }

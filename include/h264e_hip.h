@@ -106,6 +106,15 @@ int  h264e_hip_upload_planes(h264e_hip_pool_t *pool, int index, const uint8_t *c
 /* fill resident frames [first, first+n) with the synth_v1 test clip ON THE DEVICE (bench input, already in HBM) */
 int  h264e_hip_generate_synth(h264e_hip_pool_t *pool, int first, int nframes, int t0, uint32_t seed);
 int  h264e_hip_submit(h264e_hip_pool_t *pool, const h264e_hip_task_t *tasks /* [nchains] */);
+/* Launch groups: the submits of the member pools (same device, same picture size, one host thread each) are merged into ONE kernel
+ * launch per round -- the streams' jobs interleaved in dispatch order, every job with its own pool's buffers / abort word / results --
+ * so that independent streams fill each other's pipeline drains.  h264e_hip_submit of a member blocks until all members that are
+ * still in the group have submitted (or left); h264e_hip_sync returns when the merged launch has drained. */
+typedef struct h264e_hip_group h264e_hip_group_t;
+int  h264e_hip_group_create(h264e_hip_group_t **group, int device);
+int  h264e_hip_group_join(h264e_hip_group_t *group, h264e_hip_pool_t *pool);
+void h264e_hip_group_leave(h264e_hip_group_t *group, h264e_hip_pool_t *pool);
+void h264e_hip_group_destroy(h264e_hip_group_t *group);
 int  h264e_hip_sync(h264e_hip_pool_t *pool);
 /* {clusters_moved, overflow} of every chain for the LAST submitted step, in one copy (call after h264e_hip_sync) */
 int  h264e_hip_step_flags(h264e_hip_pool_t *pool, int *flags /* [nchains][2] */);

@@ -143,6 +143,7 @@ typedef struct
     int32_t mv_clusters_out[2];
     int next_idr_pic_id_state;
     int first_frame, frames;                                    /* the frames this call encoded: [first_frame, first_frame + frames) */
+    int spin_relaunches;                                        /* launches repeated because a bounded in-kernel wait expired (workgroups starved of wave slots: nothing wrong was returned) */
 } H264E_clip_stats_t;
 
 typedef struct H264E_clip_tag H264E_clip_t;
@@ -168,6 +169,12 @@ void H264E_clip_set_idle_hook(H264E_clip_t *clip, void (*hook)(void *token), voi
  * next call.  profile != 0 adds per-kernel HIP-event timing. */
 int  H264E_clip_encode(H264E_clip_t *clip, uint8_t *out, size_t cap, size_t *out_bytes, int *frame_bytes /* [frames of this call] or NULL */,
                        int profile, H264E_clip_stats_t *stats);
+/* Several independent clips of the same picture size on ONE device at the same time: each clip is encoded exactly like
+ * H264E_clip_encode does (same bytes), by a host thread of its own, and the device layer merges the clips' kernel launches so that one
+ * stream's pipeline drains (after a mis-speculated mv_clusters state) are filled by the other streams' frames.  out[i] / cap[i] /
+ * out_bytes[i] / frame_bytes[i] / stats[i] belong to clips[i] (frame_bytes and stats may be NULL).  At most 8 clips; all on the same
+ * device; large pictures allow fewer (the group refuses a clip it cannot hold safely). */
+int  H264E_clip_encode_multi(H264E_clip_t **clips, int nclips, uint8_t **out, const size_t *cap, size_t *out_bytes, int **frame_bytes, H264E_clip_stats_t *stats);
 /* back to frame 0 with the stream state of H264E_clip_open (the uploaded frames stay): encode the clip again */
 void H264E_clip_rewind(H264E_clip_t *clip);
 /* resident input frames back to host memory (whole-clip residency only; bench.py's PCIe-inclusive measurement) */

@@ -231,3 +231,23 @@ def test_random_configurations_match_oracle(name, w, h, n, kw):
     out, fs, _ = ce.encode()
     ce.close()
     assert fs == sizes and out == want
+
+
+def test_encode_multi_equals_separate_encodes():
+    """H264E_clip_encode_multi (one host thread per clip; on the GPU their launches are merged into one grid, the emulation runs them
+    side by side): every clip's stream is the one it gets alone -- also when the clips differ in content and length"""
+    P = pkg.load_pkg()
+    w, h = 176, 144
+    specs = [("synth", 9, 3, 26), ("pan", 7, 3, 26), ("noise", 5, 2, 26)]
+    encs, want = [], []
+    for name, n, gop, qp in specs:
+        c = clips.make(name, w, h, n)
+        want.append(oracle_lib.encode_clip(c, w, h, gop=gop, qp=qp))
+        e = P.ClipEncoder(w, h, n, gop=gop, qp=qp, lib=pkg.EMU_LIB)
+        e.upload(c)
+        encs.append(e)
+    res = P.ClipEncoder.encode_multi(encs)
+    for e in encs:
+        e.close()
+    for (out, sizes, st), (wbytes, wsizes) in zip(res, want):
+        assert out == wbytes and sizes == wsizes

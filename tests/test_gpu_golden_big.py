@@ -63,3 +63,43 @@ def test_full_length_stream_with_a_small_slot_ring(P, name, max_chains):
     ce.close()
     assert sizes == g["frame_bytes"]
     assert len(out) == g["bytes"] and hashlib.md5(out).hexdigest() == g["md5"]
+
+
+def test_four_streams_in_one_launch_group(P):
+    """H264E_clip_encode_multi: four copies of the 600-frame 1080p bench clip encoded at the same time on one GPU, their launches merged
+    into one grid per round (include/h264e_hip.h launch groups), each with its own mis-speculation aborts and relaunches: every stream is
+    the reference's"""
+    g = GOLDEN_BIG["bench_1080p_600"]
+    encs = []
+    for k in range(4):
+        ce = P.ClipEncoder(g["w"], g["h"], g["frames"], gop=30, qp=26)
+        ce.generate_synth()
+        encs.append(ce)
+    res = P.ClipEncoder.encode_multi(encs)
+    for ce in encs:
+        ce.close()
+    for out, sizes, st in res:
+        assert sizes == g["frame_bytes"]
+        assert len(out) == g["bytes"] and hashlib.md5(out).hexdigest() == g["md5"]
+        assert st.reencoded_gops >= 10
+
+
+def test_launch_group_of_unequal_streams(P):
+    """clips of different content, length and slice count in one launch group (CIF): the members leave the group at different times
+    and one of them runs a different kernel variant (all-intra: one wave per row)"""
+    import clips
+    import oracle_lib
+    w, h = 352, 288
+    specs = [("synth", 40, 10, 26, 0), ("pan", 24, 6, 28, 0), ("noise", 16, 1, 30, 0), ("synth", 30, 10, 26, 3)]
+    encs, want = [], []
+    for name, n, gop, qp, slices in specs:
+        c = clips.make(name, w, h, n)
+        want.append(oracle_lib.encode_clip(c, w, h, gop=gop, qp=qp, slices=slices))
+        e = P.ClipEncoder(w, h, n, gop=gop, qp=qp, slices=slices)
+        e.upload(c)
+        encs.append(e)
+    res = P.ClipEncoder.encode_multi(encs)
+    for e in encs:
+        e.close()
+    for (out, sizes, st), (wb, ws) in zip(res, want):
+        assert out == wb and sizes == ws
