@@ -693,6 +693,66 @@ static pthread_once_t g_device_lock_once = PTHREAD_ONCE_INIT;
 static void device_locks_init(void) { for (int i = 0; i < H264E_MAX_DEVICES; i++) pthread_mutex_init(&g_device_lock[i], 0); }
 #endif
 
+/*
+ * One encoder PROCESS per device.  The launch lock above only orders the launches of one process; a second process on the same GPU
+ * would put its persistent launches next to ours (bounded spins expire, launches are repeated: slow, never wrong).  The first pool a
+ * process creates on a device therefore takes an advisory lock on a file named after the device's PCI bus id and keeps it until its
+ * last pool on that device is gone; a second process fails fast with a message that says who holds the device.
+ * H264E_SHARE_DEVICE=1 skips the guard (e.g. to run two small encoders side by side on purpose).
+ */
+#ifndef H264E_EMU
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+static pthread_mutex_t g_guard_mu = PTHREAD_MUTEX_INITIALIZER;
+static int g_guard_fd[H264E_MAX_DEVICES], g_guard_pools[H264E_MAX_DEVICES], g_guard_init;
+static int process_guard_acquire(int device)
+{
+    const char *share = getenv("H264E_SHARE_DEVICE");
+    int rc = 0;
+    if ((share && atoi(share) == 1) || device < 0 || device >= H264E_MAX_DEVICES) return 0;
+    pthread_mutex_lock(&g_guard_mu);
+    if (!g_guard_init) { for (int i = 0; i < H264E_MAX_DEVICES; i++) g_guard_fd[i] = -1; g_guard_init = 1; }
+    if (g_guard_pools[device]++ == 0)
+    {
+        char bus[64] = "", path[160];
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess || !bus[0]) snprintf(bus, sizeof(bus), "dev%d", device);
+        for (char *q = bus; *q; q++) if (*q == ':' || *q == '.' || *q == '/') *q = '_';
+        snprintf(path, sizeof(path), "%s/h264e_mi355x_%s.lock", getenv("H264E_LOCK_DIR") ? getenv("H264E_LOCK_DIR") : "/tmp", bus);
+        const int fd = open(path, O_RDWR | O_CREAT, 0666);
+        if (fd >= 0)
+        {
+            if (flock(fd, LOCK_EX | LOCK_NB))
+            {
+                char who[32] = "";
+                const ssize_t n = read(fd, who, sizeof(who) - 1);
+                if (n > 0) { who[n] = 0; for (char *q = who; *q; q++) if (*q == '\n') *q = 0; }
+                snprintf(g_err, sizeof(g_err), "device %d (%s) is in use by another encoder process (pid %s): the macroblock kernel needs the device's wave slots to itself -- "
+                         "give each process its own GPU, or encode several streams in ONE process (H264E_clip_encode_multi); H264E_SHARE_DEVICE=1 overrides", device, bus, who[0] ? who : "?");
+                close(fd);
+                g_guard_pools[device]--;
+                rc = -1;
+            } else
+            {
+                char me[32];
+                const int n = snprintf(me, sizeof(me), "%ld\n", (long)getpid());
+                if (ftruncate(fd, 0) == 0 && write(fd, me, (size_t)n) != n) { /* the pid is informational */ }
+                g_guard_fd[device] = fd;
+            }
+        }       /* (no lock directory: no guard) */
+    }
+    pthread_mutex_unlock(&g_guard_mu);
+    return rc;
+}
+static void process_guard_release(int device)
+{
+    if (device < 0 || device >= H264E_MAX_DEVICES) return;
+    pthread_mutex_lock(&g_guard_mu);
+    if (g_guard_init && g_guard_pools[device] > 0 && --g_guard_pools[device] == 0 && g_guard_fd[device] >= 0) { close(g_guard_fd[device]); g_guard_fd[device] = -1; }
+    pthread_mutex_unlock(&g_guard_mu);
+}
+#endif
+
 struct h264e_hip_group;
 typedef struct h264e_hip_group h264e_hip_group_t;
 
@@ -731,6 +791,7 @@ struct h264e_hip_pool
     int *ref_sel;                        /* per chain */
     int ring_pos, pending;
     int profile, prof_launches;
+    int guarded;                         /* this pool counts in its device's process guard */
     struct h264e_hip_group *group;       /* launch group this pool's submits go through, or NULL */
     int group_round;                     /* the group round of its last submit */
     int waves;                           /* wavefronts per macroblock row forced by H264E_WAVES (1 or 2); 0 = chosen per launch (h264e_hip_submit) */
@@ -815,6 +876,9 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
     }
 #endif
     free(p->chains_host); free(p->clu_dev); free(p->ref_sel); free(p->traj_dev); free(p->traj_cur);
+#ifndef H264E_EMU
+    if (p->guarded) process_guard_release(p->device);
+#endif
     free(p);
 }
 
@@ -915,7 +979,12 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         FAIL("no HIP device: the HIP path is mandatory (there is no CPU fallback)");
     }
     if (hipSetDevice(device) != hipSuccess) { free(p); FAIL("hipSetDevice(%d) failed", device); }
-    if (hipStreamCreate(&p->stream) != hipSuccess || hipStreamCreate(&p->copy_stream) != hipSuccess) { free(p); FAIL("hipStreamCreate failed"); }
+    {
+        const int share = getenv("H264E_SHARE_DEVICE") && atoi(getenv("H264E_SHARE_DEVICE")) == 1;
+        if (process_guard_acquire(device)) { free(p); return -1; }
+        p->guarded = !share;
+    }
+    if (hipStreamCreate(&p->stream) != hipSuccess || hipStreamCreate(&p->copy_stream) != hipSuccess) { if (p->guarded) process_guard_release(device); free(p); FAIL("hipStreamCreate failed"); }
     for (int i = 0; i < TASK_RING; i++) for (int k = 0; k < 3; k++) (void)hipEventCreate(&p->ev[i][k]);
     (void)hipEventCreate(&p->ev_t0); (void)hipEventCreate(&p->ev_t1); (void)hipEventCreate(&p->ev_prep);
 #endif

@@ -102,3 +102,27 @@ def test_concurrent_clip_encoders_on_one_device_take_turns(P):
     for e in encs:
         e.close()
     assert len(set(hashlib.md5(o[0]).hexdigest() for o in outs)) == 1
+
+
+def test_second_process_on_the_same_device_fails_fast(P, tmp_path):
+    """one encoder PROCESS per device (h264e_kernels.hip process guard: an advisory lock on a file named after the device's PCI bus id):
+    while this process holds an encoder, encode_app started on the same GPU refuses with a message that names the holder; it runs
+    once the encoder here is closed, and H264E_SHARE_DEVICE=1 overrides the guard"""
+    import os
+    import subprocess
+    app = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "h264-lab_amd", "lib", "encode_app")
+    w, h, n = 176, 144, 3
+    c = clips.make("synth", w, h, n)
+    yuv = tmp_path / ("g_%dx%d.yuv" % (w, h))
+    c.tofile(yuv)
+    out = tmp_path / "o.264"
+    cmd = [app, "--input", str(yuv), "--output", str(out), "--qp", "26", "--gop", "30"]
+    e = P.Encoder(w, h, gop=30, qp=26)
+    want = b"".join(e.encode(c[t]) for t in range(n))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "in use by another encoder process (pid %d)" % os.getpid() in r.stdout, r.stdout + r.stderr
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(os.environ, H264E_SHARE_DEVICE="1"))
+    assert r.returncode == 0 and out.read_bytes() == want, r.stdout + r.stderr
+    e.close()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and out.read_bytes() == want, r.stdout + r.stderr
