@@ -77,6 +77,31 @@ def test_bench_stream_sharded_two_ranks_gloo():
     assert abs(d["value"] - frames * nmb / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]     # ONE stream: total work does not grow with the ranks
 
 
+def test_bench_stream_sharded_multi_slice_two_ranks_gloo():
+    """--shard stream --slices 8: the one strong-scaling mode that is exact as it stands -- the reference throws the mv_clusters state away
+    after every row band, so GOP blocks of a multi-slice stream need no state and nothing is encoded again (0 % re-encode, DESIGN.md 6);
+    rank0 + rank1 bytes are the oracle's 8-slice stream"""
+    import numpy as np
+    w, h, frames, world, gop, slices = 176, 144, 12, 2, 3, 8
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--shard", "stream",
+                                       "--slices", str(slices), "--frames", str(frames), "--gop", str(gop), "--size", "%dx%d" % (w, h), "--backend", "gloo",
+                                       "--lib", pkg.EMU_LIB, "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1].decode()[-2000:] for o in outs]
+    d = json.loads([l for l in outs[0][0].decode().splitlines() if l.startswith("{")][0])
+    clip = np.empty((frames, w * h * 3 // 2), np.uint8)
+    for t in range(frames):
+        oracle_lib.lib().synth_v1_frame(clip[t].ctypes.data, w, h, t, 1)
+    stream, _ = oracle_lib.encode_clip(clip, w, h, gop=gop, qp=26, slices=slices)
+    assert d["scaling"] == "strong" and d["n_gpus"] == world and d["config"]["slices_per_frame"] == slices
+    assert d["config"]["stream_md5"] == hashlib.md5(stream).hexdigest()
+    assert d["config"]["frames_encoded_again_per_rank"] == [0, 0]
+
+
 def test_gop_shards_settle_to_the_single_stream():
     """h264-lab_amd/shard.py in one process: shards that start from a speculated mv_clusters state, are re-validated with the exact
     one and encode again from the first GOP that consumed different candidates; the fast-pan clip forces such boundaries, row-band
