@@ -894,7 +894,10 @@ static int build_order(h264e_hip_pool_t *p, int jobs, int narrow)
 {
     const h264e_geom_t &G = p->G;
     const int rows = G.nmby + 1, total = jobs*rows, lag = narrow ? H264E_NARROW_FRAME_LAG : H264E_FRAME_LAG, maxkey = lag*(jobs - 1) + 2*(rows - 1);
-    const int bands = getenv("H264E_XCD_BANDS") ? atoi(getenv("H264E_XCD_BANDS")) : 0;
+    /* measured with the two-wave kernel (gpurun_out/r3_bands1): 8 bands halve FETCH_SIZE everywhere (1080p: 1896 -> 919 MB per launch; fetch +
+     * write 2827 -> 1744 MB) -- and cost 2-4 % speed at 1080p and below, but GAIN 8 % at 4K, where a frame's rows no longer fit the L2s at
+     * random: on by default from 4K up */
+    const int bands = getenv("H264E_XCD_BANDS") ? atoi(getenv("H264E_XCD_BANDS")) : (G.nmb >= 30000 ? 8 : 0);
     uint32_t *ord = p->order_host;
     int *start = (int *)calloc((size_t)maxkey + 2, sizeof(int));
     uint32_t *tmp = bands ? (uint32_t *)malloc(sizeof(uint32_t)*(size_t)total) : ord;

@@ -15,7 +15,7 @@ echo "tests rc=$rc" | tee -a $OUT/tests.log
 tail -5 $OUT/tests.log
 [ $rc -ne 0 ] && exit $rc
 export H264E_QUIET=1
-for wv in 2 1; do
+for wv in ${WAVES_LIST:-2 1}; do
   export H264E_WAVES=$wv
   echo "--- H264E_WAVES=$wv" >> $OUT/configs.txt
   for cfg in "600 1920 1080 30 26 0 0" "600 1920 1080 30 26 8 0" "600 1920 1080 1 26 0 0" ${EXTRA_CFGS}; do
