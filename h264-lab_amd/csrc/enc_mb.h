@@ -11,6 +11,7 @@
 #ifndef H264E_ENC_MB_H
 #define H264E_ENC_MB_H
 
+#include <stddef.h>
 #include "enc_kernels.h"
 
 /* predictor context of the motion search (H:3646-3671 saves and restores it around every partitioning; here every partition type works on
@@ -71,17 +72,7 @@ struct RowLds
     int early_bound;                                /* an upper bound of the inter cost, known right after the candidate evaluation (f_bound) */
 
     MbBuf mb[2];
-
-    /* ---- search side, per macroblock */
     alignas(4) uint8_t trec[72];                    /* staged record of the macroblock above (+ 8 bytes of the one above-right) */
-    mv32 part_mv[4][4], part_mvd[4][4];
-    GCtx gctx[4];                                   /* the motion search's predictor context, one copy per partition type (lane group) */
-    int gcost[4], gnum[4];                          /* cost and number of partitions of every partition type searched */
-    alignas(16) uint8_t win[WIN_W*WIN_STRIDE + 16];  /* reference luma window around the current macroblock */
-    alignas(16) uint8_t skip_pred[256];
-    alignas(16) uint8_t skip_pred_c[128];           /* chroma of the early-skip test (the reconstruction side predicts chroma again for itself) */
-    alignas(16) uint8_t gtest[4][256];              /* prediction of every partition type searched */
-    alignas(16) uint8_t gscr[GSCR_BYTES];           /* sub-pel search: the full-sample block and the three half-sample planes of the partition a group works on */
 
     /* ---- reconstruction side, per macroblock */
     int8_t i4_mode[16];
@@ -103,7 +94,20 @@ struct RowLds
     DfTab dftab;
     int qconst[6];                                  /* this frame's decision constants: lambda_mv, lambda_q4, skip_thr, skip_thr_i4, lambda_i4, lambda_i16 */
     uint16_t qdat[2][42];                           /* this frame's quantizer tables, copied from the task */
+
+    /* ---- search side, per macroblock.  LAST in the struct: the intra-only kernel variant never touches these and allocates the
+     * struct only up to here (ROWLDS_INTRA_BYTES), which is what lets twice as many of its workgroups fit a CU */
+    mv32 part_mv[4][4], part_mvd[4][4];
+    GCtx gctx[4];                                   /* the motion search's predictor context, one copy per partition type (lane group) */
+    int gcost[4], gnum[4];                          /* cost and number of partitions of every partition type searched */
+    alignas(16) uint8_t win[WIN_W*WIN_STRIDE + 16];  /* reference luma window around the current macroblock */
+    alignas(16) uint8_t skip_pred[256];
+    alignas(16) uint8_t skip_pred_c[128];           /* chroma of the early-skip test (the reconstruction side predicts chroma again for itself) */
+    alignas(16) uint8_t gtest[4][256];              /* prediction of every partition type searched */
+    alignas(16) uint8_t gscr[GSCR_BYTES];           /* sub-pel search: the full-sample block and the three half-sample planes of the partition a group works on */
+
 };
+#define ROWLDS_INTRA_BYTES offsetof(RowLds, part_mv)
 
 struct MbCtx
 {

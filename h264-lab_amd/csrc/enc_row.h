@@ -12,6 +12,10 @@
 
 #include "enc_mb.h"
 
+#define GEOM_WIDE 0
+#define GEOM_NARROW 1
+#define GEOM_INTRA 2
+
 /* the chain's buffers with explicit HBM address spaces (pointers loaded from a struct are generic otherwise: FLAT
  * instructions, and the compiler has to treat what they load as lane-varying) */
 struct ChainG
@@ -147,10 +151,10 @@ DEV void load_input(MbBuf &B, const h264e_geom_t &G, const RowTask &T, int mbx, 
 /* What macroblock (x, row) needs that does not depend on the row above: its input samples and, for P slices, the
  * reference window (the caller has waited for the temporal dependency).  Issued BEFORE the wait for the row above, so
  * the HBM latency of these loads overlaps with that wait. */
-DEV void row_prefetch(RowLds &L, const h264e_geom_t &G, const RowTask &T, int row, int x)
+template <int GEOM> DEV void row_prefetch(RowLds &L, const h264e_geom_t &G, const RowTask &T, int row, int x)
 {
     load_input(L.mb[x & 1], G, T, x, row);
-    if (T.slice_type == 0)
+    if (GEOM != GEOM_INTRA && T.slice_type == 0)
     {
         Plane P;
         P.p = (const gu8 *)T.ref[0]; P.w = G.W; P.h = G.H; P.stride = G.W;
@@ -167,12 +171,14 @@ DEV void row_prefetch(RowLds &L, const h264e_geom_t &G, const RowTask &T, int ro
  * candidates of x + 1 need the reconstruction of x (left column) -- so with two wavefronts per row (h264e_kernels.hip) the search
  * wave works on x + 1 while the reconstruction wave writes x, then tests the intra candidates of x + 1.  With one wavefront (and in
  * the emulation) the three run one after the other; the decisions are the same either way.
- * NARROW: compile-time choice of the reference-window geometry (h264e_dev.h).
+ * GEOM: compile-time kernel variant -- GEOM_WIDE / GEOM_NARROW = the reference-window geometry (h264e_dev.h); GEOM_INTRA = a launch of
+ * intra frames only: the inter decision, the reference window and the inter chroma prediction are compiled out (and with them most of
+ * the register pressure: that variant runs at twice the waves per SIMD).
  * row0 / row1: first row and end row of the slice (row band) this row belongs to -- the whole picture for one slice per frame.
  * A slice is encoded like a picture of its own as far as neighbour availability, contexts and deblocking are concerned
  * (h264-lab.h:3605-3622 mb_avail_flag relative to slice.start_mb_num, h264-lab.h:5799-5808 no filtering across its top edge).
  */
-template <bool NARROW> DEV void mb_ctx_init(MbCtx &m, RowLds &L, const h264e_geom_t &G, const RowTask &T, int row, int x, int row0, int side)
+template <int GEOM> DEV void mb_ctx_init(MbCtx &m, RowLds &L, const h264e_geom_t &G, const RowTask &T, int row, int x, int row0, int side)
 {
     const bool have_top = row > row0;
     m.G = &G;
@@ -192,20 +198,20 @@ template <bool NARROW> DEV void mb_ctx_init(MbCtx &m, RowLds &L, const h264e_geo
     m.lambda_mv = uni(L.qconst[0]); m.lambda_q4 = uni(L.qconst[1]); m.skip_thr = uni(L.qconst[2]);
     m.skip_thr_i4 = uni(L.qconst[3]); m.lambda_i4 = uni(L.qconst[4]); m.lambda_i16 = uni(L.qconst[5]);
     m.rv.dep = (const GLOBAL_AS int *)T.dep_progress; m.rv.nmbx = G.nmbx; m.rv.nmby = G.nmby;
-    m.rv.P = m.ref[0]; m.rv.win = (const lu8 *)L.win; m.rv.has_win = T.slice_type == 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
-    m.rv.vw = NARROW ? H264E_NARROW_VW : WIN_W; m.rv.vh = NARROW ? H264E_NARROW_VH : WIN_W; m.rv.far = &L.far_reads[side]; m.rv.fail = &L.far_fail[side]; m.rv.slice_row = L.slice_row; m.rv.nslices = T.nslices; m.rv.spin_limit = G.spin_limit;
+    m.rv.P = m.ref[0]; m.rv.win = (const lu8 *)L.win; m.rv.has_win = GEOM != GEOM_INTRA && T.slice_type == 0; m.rv.wx0 = x*16 - WIN_M; m.rv.wy0 = row*16 - WIN_M;
+    m.rv.vw = GEOM == GEOM_NARROW ? H264E_NARROW_VW : WIN_W; m.rv.vh = GEOM == GEOM_NARROW ? H264E_NARROW_VH : WIN_W; m.rv.far = &L.far_reads[side]; m.rv.fail = &L.far_fail[side]; m.rv.slice_row = L.slice_row; m.rv.nslices = T.nslices; m.rv.spin_limit = G.spin_limit;
 }
 
 /* search side.  The input macroblock, the reference window (row_prefetch) and the records of the row above (load_top) are already in
  * LDS.  sig (inter_choose): sig.noskip() is called once the
  * early-skip test has failed (the reconstruction side may start on the intra candidates then). */
 struct NoSignals { DEVM void noskip() const {} DEVM void bound(int) const {} };
-template <bool NARROW, class SIG> DEV void mb_search(RowLds &L, MbBuf &B, const h264e_geom_t &G, const RowTask &T, int row, int x, int row0, SIG sig)
+template <int GEOM, class SIG> DEV void mb_search(RowLds &L, MbBuf &B, const h264e_geom_t &G, const RowTask &T, int row, int x, int row0, SIG sig)
 {
     MbCtx m;
-    mb_ctx_init<NARROW>(m, L, G, T, row, x, row0, 0);
+    mb_ctx_init<GEOM>(m, L, G, T, row, x, row0, 0);
     STAMP(L, 1);
-    if (T.slice_type == 0) inter_choose(L, B, m, sig);
+    if (GEOM != GEOM_INTRA && T.slice_type == 0) inter_choose(L, B, m, sig);
     STAMP(L, 7);
     B.type = m.type; B.cost = m.cost; B.used_cand = m.used_cand; B.mv_skip_pred = m.mv_skip_pred;
     wave_sync();
@@ -260,11 +266,11 @@ template <class P> DEV bool mb_intra_decide(RowLds &L, MbBuf &B, MbCtx &m, const
 }
 
 /* reconstruction side, second half */
-template <bool NARROW> DEV void mb_recon_write(RowLds &L, MbBuf &B, MbCtx &m, const h264e_geom_t &G, const ChainG &C, const RowTask &T, int row, int x, int row0, int row1)
+template <int GEOM> DEV void mb_recon_write(RowLds &L, MbBuf &B, MbCtx &m, const h264e_geom_t &G, const ChainG &C, const RowTask &T, int row, int x, int row0, int row1)
 {
     const bool have_top = row > row0;
     GLOBAL_AS h264e_mbbottom_t *rowrec = C.bottom + (size_t)row*G.nmbx;
-    if (m.type >= 5) wave_pred_chroma(L.pred_c, L.pix_left + 16, B.pix_top + 16, m.avail, m.i16_mode);
+    if (GEOM == GEOM_INTRA || m.type >= 5) wave_pred_chroma(L.pred_c, L.pix_left + 16, B.pix_top + 16, m.avail, m.i16_mode);
     else predict_chroma_inter(B, m, L.pred_c);
 
     STAMP(L, 10);
@@ -436,15 +442,15 @@ template <bool NARROW> DEV void mb_recon_write(RowLds &L, MbBuf &B, MbCtx &m, co
 }
 
 /* the three phases one after the other: one wavefront per row, and the emulation */
-template <bool NARROW> DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const RowTask &T, int row, int x, int row0, int row1)
+template <int GEOM> DEV void row_step(RowLds &L, const h264e_geom_t &G, const ChainG &C, const RowTask &T, int row, int x, int row0, int row1)
 {
     MbBuf &B = L.mb[x & 1];
     MbCtx m;
     load_top(L, B, G, C.bottom + (size_t)(row - 1)*G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, row > row0);
-    mb_search<NARROW>(L, B, G, T, row, x, row0, NoSignals());
-    mb_ctx_init<NARROW>(m, L, G, T, row, x, row0, 1);
+    mb_search<GEOM>(L, B, G, T, row, x, row0, NoSignals());
+    mb_ctx_init<GEOM>(m, L, G, T, row, x, row0, 1);
     mb_intra_decide(L, B, m, T, InterIsThere());
-    mb_recon_write<NARROW>(L, B, m, G, C, T, row, x, row0, row1);
+    mb_recon_write<GEOM>(L, B, m, G, C, T, row, x, row0, row1);
 }
 
 DEV void row_end(RowLds &L, const h264e_geom_t &G, const ChainG &C, int row)

@@ -112,10 +112,19 @@ struct InterFromSearchWave
 #ifndef H264E_WPE1
 #define H264E_WPE1 2
 #endif
-template <bool NARROW, int WAVES>
-__global__ void __launch_bounds__(64*WAVES, WAVES == 2 ? H264E_WPE2 : H264E_WPE1) h264e_mb_kernel(h264e_geom_t G, const h264e_frame_task_t *tasks, const uint32_t *order)
+#ifndef H264E_WPEI
+#define H264E_WPEI 4
+#endif
+/* OCC: wavefronts per SIMD the register allocation aims at.  The two-wave kernel exists twice: at 3 (168 VGPRs, ~60 spilled) and at 4
+ * (128 VGPRs, ~110 spilled).  Measured (gpurun_out/r3_wpe4): more residency beats fewer spills where a launch is bound by the rows in
+ * flight -- 8K 6.6 -> 8.9 M MB/s, 8 slices at 1080p 21.2 -> 22.1 M -- and loses where it is latency bound (1080p single slice 9.8 -> 9.2 M,
+ * lone frame 10.3 -> 11.1 ms); h264e_hip_submit picks per launch. */
+template <int GEOM, int WAVES, int OCC>
+__global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G, const h264e_frame_task_t *tasks, const uint32_t *order)
 {
-    __shared__ RowLds L;
+    /* (the intra-only variant allocates the row state without the search-side buffers at its end: enc_mb.h ROWLDS_INTRA_BYTES) */
+    __shared__ __attribute__((aligned(16))) unsigned char L_bytes[GEOM == GEOM_INTRA ? ROWLDS_INTRA_BYTES : sizeof(RowLds)];
+    RowLds &L = *reinterpret_cast<RowLds *>(L_bytes);
     const int wv = WAVES == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;     /* which wavefront of the workgroup */
 #ifdef H264E_LDS_PAD
     /* diagnostic build (Makefile `halfres`): extra LDS per workgroup so that fewer workgroups fit a CU -- what single-stream throughput
@@ -257,6 +266,7 @@ __global__ void __launch_bounds__(64*WAVES, WAVES == 2 ? H264E_WPE2 : H264E_WPE1
         const GLOBAL_AS int *abort_word = (const GLOBAL_AS int *)uniptr(T.abort_word);
         const int launch_id = uni(T.launch_id);
         int seen = 0, seen_dep = 0;
+        constexpr bool NARROW = GEOM == GEOM_NARROW;
         constexpr int DEP_ROWS = NARROW ? H264E_NARROW_DEP_ROWS : H264E_DEP_ROWS, DEP_COLS = NARROW ? H264E_NARROW_DEP_COLS : H264E_DEP_COLS;
         /* temporal wavefront: the reference window covers macroblock rows row-2 .. row+DEP_ROWS of the frame being referenced.
          * Inside one slice the lowest of them is the last to get there; with row-band slices the bands advance independently, so
@@ -299,7 +309,7 @@ __global__ void __launch_bounds__(64*WAVES, WAVES == 2 ? H264E_WPE2 : H264E_WPE1
             STAMP(L, 13);
             if (WAVES == 2 && !st && x >= 2) st = lds_wait(&L.f_wdone, x - 1, &L.f_stop);
             STAMP(L, 23);
-            if (!st) row_prefetch(L, G, RT, row, x);
+            if (!st) row_prefetch<GEOM>(L, G, RT, row, x);
             STAMP(L, 0);
             /* ... so that their latency overlaps with the wait for the row above */
             if (!st && seen < need)
@@ -325,8 +335,8 @@ __global__ void __launch_bounds__(64*WAVES, WAVES == 2 ? H264E_WPE2 : H264E_WPE1
                 }
                 return;
             }
-            if (WAVES == 1) row_step<NARROW>(L, G, C, RT, row, x, row0, row1);
-            else mb_search<NARROW>(L, L.mb[x & 1], G, RT, row, x, row0, SearchSignals{ &L, x + 1 });
+            if (WAVES == 1) row_step<GEOM>(L, G, C, RT, row, x, row0, row1);
+            else mb_search<GEOM>(L, L.mb[x & 1], G, RT, row, x, row0, SearchSignals{ &L, x + 1 });
             {
                 /* a far reference read of this macroblock waited in vain (rv_wait_rect): what it encoded is not trustworthy */
                 const int ff = uni(L.far_fail[0]) | (WAVES == 1 ? uni(L.far_fail[1]) : 0);
@@ -364,13 +374,13 @@ __global__ void __launch_bounds__(64*WAVES, WAVES == 2 ? H264E_WPE2 : H264E_WPE1
         {
             MbBuf &B = L.mb[x & 1];
             MbCtx m;
-            mb_ctx_init<NARROW>(m, L, G, RT, row, x, row0, 1);
+            mb_ctx_init<GEOM>(m, L, G, RT, row, x, row0, 1);
             int ff = 0;
             if (!mb_intra_decide(L, B, m, RT, InterFromSearchWave{ &L, x + 1 })) ff = uni(flag_get(&L.f_stop));
             else
             {
                 flag_set(&L.f_decided, x + 1);
-                mb_recon_write<NARROW>(L, B, m, G, C, RT, row, x, row0, row1);
+                mb_recon_write<GEOM>(L, B, m, G, C, RT, row, x, row0, row1);
                 ff = uni(L.far_fail[1]);
                 if (ff) { ff = ff < -2 ? -2 : ff; flag_set(&L.f_stop, ff); }
             }
@@ -973,7 +983,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     }
     p->frame_bytes = (size_t)width*height*3/2;
     p->waves = getenv("H264E_WAVES") ? atoi(getenv("H264E_WAVES")) : 0;                  /* 1 / 2: forced (A-B measurements); else chosen per launch */
-    if (p->waves < 0 || p->waves > 2) p->waves = 0;
+    if (p->waves != 1 && p->waves != 2 && p->waves != 4) p->waves = 0;
 #ifndef H264E_EMU
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -1309,17 +1319,24 @@ extern "C" void h264e_hip_release(h264e_hip_pool_t *p)
 }
 
 #ifndef H264E_EMU
-static void launch_mb_kernel(const h264e_geom_t &G, int narrow, int waves, unsigned nblocks, const h264e_frame_task_t *td, const uint32_t *od, hipStream_t st)
+/* variant: 0 = intra frames only (one wave per row, 4 per SIMD), 1 = one wave per row, 2 = two waves per row (3 per SIMD), 4 = two waves
+ * per row at 4 per SIMD */
+static void launch_mb_kernel(const h264e_geom_t &G, int narrow, int variant, unsigned nblocks, const h264e_frame_task_t *td, const uint32_t *od, hipStream_t st)
 {
     const dim3 grid(nblocks);
-    if (waves == 2)
+    if (variant == 0) hipLaunchKernelGGL((h264e_mb_kernel<GEOM_INTRA, 1, H264E_WPEI>), grid, dim3(64), 0, st, G, td, od);
+    else if (variant == 4)
     {
-        if (narrow) hipLaunchKernelGGL((h264e_mb_kernel<true, 2>), grid, dim3(128), 0, st, G, td, od);
-        else hipLaunchKernelGGL((h264e_mb_kernel<false, 2>), grid, dim3(128), 0, st, G, td, od);
+        if (narrow) hipLaunchKernelGGL((h264e_mb_kernel<GEOM_NARROW, 2, 4>), grid, dim3(128), 0, st, G, td, od);
+        else hipLaunchKernelGGL((h264e_mb_kernel<GEOM_WIDE, 2, 4>), grid, dim3(128), 0, st, G, td, od);
+    } else if (variant == 2)
+    {
+        if (narrow) hipLaunchKernelGGL((h264e_mb_kernel<GEOM_NARROW, 2, H264E_WPE2>), grid, dim3(128), 0, st, G, td, od);
+        else hipLaunchKernelGGL((h264e_mb_kernel<GEOM_WIDE, 2, H264E_WPE2>), grid, dim3(128), 0, st, G, td, od);
     } else
     {
-        if (narrow) hipLaunchKernelGGL((h264e_mb_kernel<true, 1>), grid, dim3(64), 0, st, G, td, od);
-        else hipLaunchKernelGGL((h264e_mb_kernel<false, 1>), grid, dim3(64), 0, st, G, td, od);
+        if (narrow) hipLaunchKernelGGL((h264e_mb_kernel<GEOM_NARROW, 1, H264E_WPE1>), grid, dim3(64), 0, st, G, td, od);
+        else hipLaunchKernelGGL((h264e_mb_kernel<GEOM_WIDE, 1, H264E_WPE1>), grid, dim3(64), 0, st, G, td, od);
     }
 }
 #endif
@@ -1357,9 +1374,9 @@ static int group_launch_locked(h264e_hip_group_t *g)
 {
     int rc = 0;
     if (hipSetDevice(g->device) != hipSuccess) rc = -1;
-    for (int variant = 0; variant < 4 && !rc; variant++)
+    for (int variant = 0; variant < 10 && !rc; variant++)
     {
-        const int narrow = variant & 1, waves = 1 + (variant >> 1);
+        const int narrow = variant & 1, waves = variant >> 1;
         int idx[H264E_GROUP_MAX], n = 0, jobs = 0;
         for (int k = 0; k < g->nmembers; k++)
             if (g->pend[k] && g->pend_narrow[k] == narrow && g->pend_waves[k] == waves) { idx[n++] = k; jobs += g->pend_jobs[k]; }
@@ -1530,7 +1547,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     if (p->pending >= TASK_RING - 1 && h264e_hip_sync(p)) return -1;
     h264e_frame_task_t *host = (h264e_frame_task_t *)calloc((size_t)p->nchains, sizeof(h264e_frame_task_t));
     if (!host) FAIL("out of host memory");
-    int any = 0, any_narrow = 0, any_wide = 0, njobs = 0, all_intra = 1;
+    int any = 0, any_narrow = 0, any_wide = 0, njobs = 0, all_intra = 1, max_slices = 1;
     const int launch_id = ++p->launch_counter;
     for (int c = 0; c < p->nchains; c++)
     {
@@ -1546,6 +1563,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         }
         any = 1; njobs = c + 1;
         if (t.slice_type != 2) all_intra = 0;
+        if (t.nslices > max_slices) max_slices = t.nslices;
         const uint8_t *f = p->clip + p->frame_bytes*(size_t)t.frame_index;
         d.in[0] = f; d.in[1] = f + (size_t)G.width*G.height; d.in[2] = d.in[1] + (size_t)(G.width/2)*(G.height/2);
         d.in_stride[0] = G.width; d.in_stride[1] = d.in_stride[2] = G.width/2;
@@ -1670,7 +1688,13 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             for (int k = 0; k < T.nslices; k++)
                 if (row >= T.slice_row[k] && row < T.slice_row[k + 1]) { row0 = T.slice_row[k]; row1 = T.slice_row[k + 1]; }
             const RowTask RT = rowtask_load(T);
-            for (int x = 0; x < G.nmbx; x++) { row_prefetch(*L, G, RT, row, x); if (T.narrow) row_step<true>(*L, G, C, RT, row, x, row0, row1); else row_step<false>(*L, G, C, RT, row, x, row0, row1); }
+            for (int x = 0; x < G.nmbx; x++)
+            {
+                /* the three kernel variants, chosen like the launcher does */
+                if (T.slice_type == 2 && all_intra) { row_prefetch<GEOM_INTRA>(*L, G, RT, row, x); row_step<GEOM_INTRA>(*L, G, C, RT, row, x, row0, row1); }
+                else if (T.narrow) { row_prefetch<GEOM_NARROW>(*L, G, RT, row, x); row_step<GEOM_NARROW>(*L, G, C, RT, row, x, row0, row1); }
+                else { row_prefetch<GEOM_WIDE>(*L, G, RT, row, x); row_step<GEOM_WIDE>(*L, G, C, RT, row, x, row0, row1); }
+            }
             row_end(*L, G, C, row);
             free(L);
         }
@@ -1737,7 +1761,9 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
      * the better trade wherever a launch is latency bound (single-slice streams: mis-speculation events; rate control and the
      * frame-at-a-time API: a few frames per launch) and still level for multi-slice streams; an all-intra launch has nothing to
      * search and no events: one wave per row, twice the rows in flight (22.4 vs 18.3 M MB/s at 1080p) */
-    const int waves = p->waves ? p->waves : all_intra ? 1 : 2;
+    /* (waves = 0 selects the intra-only variant of the one-wave kernel: no inter code, half the registers, twice the rows in flight) */
+    /* (... and 4 the two-wave kernel allocated for 4 waves per SIMD: launches bound by the rows in flight -- 8K-class pictures, many slices) */
+    const int waves = p->waves ? p->waves : all_intra ? 0 : (G.nmb >= 60000 || max_slices >= 4) ? 4 : 2;
     if (p->group)
     {
         /* member of a launch group: the launch is merged with the other members' (group_launch_locked) */
