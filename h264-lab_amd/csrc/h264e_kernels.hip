@@ -115,10 +115,9 @@ struct InterFromSearchWave
 #ifndef H264E_WPEI
 #define H264E_WPEI 4
 #endif
-/* OCC: wavefronts per SIMD the register allocation aims at.  The two-wave kernel exists twice: at 3 (168 VGPRs, ~60 spilled) and at 4
- * (128 VGPRs, ~110 spilled).  Measured (gpurun_out/r3_wpe4): more residency beats fewer spills where a launch is bound by the rows in
- * flight -- 8K 6.6 -> 8.9 M MB/s, 8 slices at 1080p 21.2 -> 22.1 M -- and loses where it is latency bound (1080p single slice 9.8 -> 9.2 M,
- * lone frame 10.3 -> 11.1 ms); h264e_hip_submit picks per launch. */
+/* OCC: wavefronts per SIMD the register allocation aims at.  The two-wave kernel exists twice: at 3 (164 VGPRs, nothing spilled) and at 4
+ * (128 VGPRs, ~30 spilled); h264e_hip_submit picks per launch (more residency wins where a launch is bound by the rows in flight, fewer
+ * spills where it is pure latency). */
 template <int GEOM, int WAVES, int OCC>
 __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G, const h264e_frame_task_t *tasks, const uint32_t *order)
 {
@@ -1763,7 +1762,11 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
      * search and no events: one wave per row, twice the rows in flight (22.4 vs 18.3 M MB/s at 1080p) */
     /* (waves = 0 selects the intra-only variant of the one-wave kernel: no inter code, half the registers, twice the rows in flight) */
     /* (... and 4 the two-wave kernel allocated for 4 waves per SIMD: launches bound by the rows in flight -- 8K-class pictures, many slices) */
-    const int waves = p->waves ? p->waves : all_intra ? 0 : (G.nmb >= 60000 || max_slices >= 4) ? 4 : 2;
+    /* measured with the final register allocation (gpurun_out/r3_lane4): 4 per SIMD wins wherever a launch offers enough rows to fill the
+     * chip (8 slices 20.6 -> 23.3 M MB/s, 8K 6.6 -> 9.1 M, 4K 14.8 -> 15.3 M, 1080p single slice 9.56 -> 9.61 M); launches of a few frames
+     * (rate control, the frame-at-a-time API) are pure latency and keep the 3-per-SIMD kernel with its fewer spills (10.5 vs 10.9 ms) */
+    const int waves = p->waves ? p->waves : all_intra ? 0 : (njobs*G.nmby >= 1536) ? 4 : 2;
+    (void)max_slices;
     if (p->group)
     {
         /* member of a launch group: the launch is merged with the other members' (group_launch_locked) */
