@@ -195,6 +195,28 @@ def multi_slice_pass(P, frames, w, h, gop, slices=8):
             "note": "a different (multi-slice) bitstream: the reference built with -DH264E_MAX_THREADS and run with --threads %d; not the headline" % slices}
 
 
+def multi_stream_pass(P, frames, w, h, gop, clips=4):
+    """`clips` independent copies of the clip encoded AT THE SAME TIME on the one GPU (H264E_clip_encode_multi: the streams' launches
+    merged into one grid per round, so that one stream's pipeline drains are filled by the others): aggregate rate, never the headline"""
+    encs = []
+    for _ in range(clips):
+        e = P.ClipEncoder(w, h, frames, gop=gop, qp=QP, speed=0)
+        e.generate_synth(0, frames, t0=0, seed=1)
+        encs.append(e)
+    P.ClipEncoder.encode_multi(encs)
+    t0 = time.time()
+    res = P.ClipEncoder.encode_multi(encs)
+    dt = time.time() - t0
+    for e in encs:
+        e.close()
+    nmb = ((w + 15) // 16) * ((h + 15) // 16)
+    want = _golden_md5(w, h, frames, gop, QP)
+    md5s = [hashlib.md5(r[0]).hexdigest() for r in res]
+    return {"clips": clips, "value": clips * frames * nmb / dt, "unit": "macroblocks/s", "fps": clips * frames / dt,
+            "parity_full_stream": all(m == want for m in md5s) if want else None, "relaunches": [r[2].reencoded_gops for r in res],
+            "note": "aggregate of %d single-slice streams in one launch group on ONE GPU; every stream md5-checked against the reference; not the headline" % clips}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -369,6 +391,11 @@ def main():
                 line["multi_slice"] = multi_slice_pass(P, frames, w, h, gop)
             except Exception as e:
                 line["multi_slice"] = {"value": None, "note": "failed: %r" % (e,)}
+            try:
+                enc.close()             # (its slot ring is the largest allocation: give it back before four more encoders open)
+                line["multi_stream"] = multi_stream_pass(P, frames, w, h, gop)
+            except Exception as e:
+                line["multi_stream"] = {"value": None, "note": "failed: %r" % (e,)}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 cb, ref_bytes = cpu_baseline()

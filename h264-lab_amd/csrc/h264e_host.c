@@ -545,13 +545,18 @@ static int impl_of(const henc_t *e, impl_t *out)
     return ok;
 }
 
-/* with the lock held: release every entry whose owner address lies in [p, p + n) */
+/* with the lock held: release every entry whose persist blob [owner, owner + owner_bytes) OVERLAPS [p, p + n): the memory of an abandoned
+ * encoder may begin below a new allocation and still reach into it */
 static void reclaim_range(const void *p, size_t n)
 {
+    const char *lo = (const char *)p, *hi = lo + (n ? n : 1);
     int i;
     for (i = 0; i < g_impl_cap; i++)
-        if (g_impl[i].owner && (const char *)g_impl[i].owner >= (const char *)p && (const char *)g_impl[i].owner < (const char *)p + (n ? n : 1))
-            impl_release(g_impl + i);
+        if (g_impl[i].owner)
+        {
+            const char *olo = (const char *)g_impl[i].owner, *ohi = olo + (g_impl[i].owner_bytes ? g_impl[i].owner_bytes : 1);
+            if (olo < hi && lo < ohi) impl_release(g_impl + i);
+        }
 }
 
 void H264E_close(H264E_persist_t *p)
@@ -627,6 +632,11 @@ int H264E_init(H264E_persist_t *p, const H264E_create_param_t *par)
         return H264E_STATUS_BAD_PARAMETER;
     }
     ref_sizes(par, &sp, &ss);
+    /* whatever lived in this memory goes FIRST (re-init of the same blob, or of memory an abandoned encoder lived in): a re-init does not
+     * need the device memory twice, and a failure below does not leave an entry registered for a blob that has been zeroed */
+    pthread_mutex_lock(&g_reg_lock);
+    reclaim_range(p, (size_t)sp);
+    pthread_mutex_unlock(&g_reg_lock);
     memset(e, 0, sizeof(*e));
     e->param = *par;
     seq_init(&e->seq, par->width, par->height, par->vbv_size_bytes, par->sps_id);
@@ -639,7 +649,7 @@ int H264E_init(H264E_persist_t *p, const H264E_create_param_t *par)
     if (!par->const_input_flag) fresh.recon = (uint8_t *)malloc((size_t)e->seq.w*e->seq.h*3/2);
     fresh.owner = e; fresh.owner_bytes = (size_t)sp;
     pthread_mutex_lock(&g_reg_lock);
-    reclaim_range(p, (size_t)sp);               /* re-init of the same blob, or of memory an abandoned encoder lived in */
+    reclaim_range(p, (size_t)sp);               /* (another thread may have registered an overlapping blob meanwhile) */
     for (i = 0; i < g_impl_cap && g_impl[i].owner; i++) {}
     if (i == g_impl_cap)
     {
@@ -823,6 +833,7 @@ struct H264E_clip_tag
     int32_t (*used_store)[2];               /* [nframes] frame-constant candidates it was given ... */
     int32_t **permb_store;                  /* [nframes] ... or the per-macroblock trajectory it was given */
     uint64_t *ssd_out;                      /* optional: [3] sums of squared differences input vs reconstruction per encoded frame of a call */
+    int recon_floor;                        /* rate control: frames below this one may have been overwritten by hedge leaves (H264E_clip_read_recon) */
     int32_t *traj;                          /* scratch: walked trajectory [nmb][2] */
     uint8_t *big; size_t big_cap;           /* scratch: NALs of a frame that did not fit the host mirror */
     h264e_hip_task_t *tasks;                /* scratch [ring] */
@@ -842,7 +853,7 @@ void H264E_clip_rewind(H264E_clip_t *c)
     c->next = 0;
     c->state[0] = c->par.mv_clusters_in[0]; c->state[1] = c->par.mv_clusters_in[1];
     free(c->first_arr); c->first_arr = NULL; c->first_dev = 0;
-    c->first_row = 0; c->have_after = 0;
+    c->first_row = 0; c->have_after = 0; c->recon_floor = 0;
     /* reference-window geometry (h264e_dev.h): narrow = consecutive frames 4 macroblock steps apart, as long as vectors rarely
      * reach more than 12 samples right / down of their macroblock; wide (7 steps) for the rest of the clip otherwise.  Large
      * pictures already fill the GPU's resident workgroups with the wide geometry: the narrow one only pays below ~12k macroblocks */
@@ -1020,6 +1031,9 @@ int H264E_clip_download(H264E_clip_t *c, int first, int nframes, uint8_t *i420)
 int H264E_clip_read_recon(H264E_clip_t *c, int frame, uint8_t *dst)
 {
     if (!c || !dst || frame < 0 || frame >= c->next || frame < c->next - (c->ring - 1)) return -1;
+    /* rate control: the launches' hedge leaves (alternative QPs of frames in flight) are encoded in spare slots of the ring, i.e. over
+     * the pictures of older frames -- only the frames accepted since the last launch's first frame are guaranteed to be intact */
+    if (c->par.kbps > 0 && frame < c->recon_floor) return -1;
     return h264e_hip_read_recon_slot(c->pool, frame % c->ring, dst);
 }
 
@@ -1203,6 +1217,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
                     hedge_level[nh] = k; hedge_qp[nh] = q; nh++;
                 }
         }
+        if (nh) c->recon_floor = n;             /* the leaves' slots held the pictures of frames n - K + F .. : gone now */
         stats.rounds++;
         c->have_after = 0;
         const double t_submit = now_ms();

@@ -809,6 +809,7 @@ struct h264e_hip_pool
 #ifndef H264E_EMU
     hipStream_t stream;
     hipStream_t copy_stream;             /* uploads that overlap with kernels on `stream` */
+    hipStream_t abort_stream;            /* carries nothing but abort requests (h264e_hip_stream_abort) */
     hipEvent_t ev_t0, ev_t1, ev_prep;
     hipEvent_t ev[TASK_RING][3];         /* per pending submit: before / between / after the two kernels */
     int ev_pending;
@@ -870,6 +871,7 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->copy_stream) (void)hipStreamSynchronize(p->copy_stream);
+    if (p->abort_stream) (void)hipStreamSynchronize(p->abort_stream);
 #endif
     device_release(p);
     host_free(p->hheap);
@@ -882,6 +884,7 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
         (void)hipEventDestroy(p->ev_t0); (void)hipEventDestroy(p->ev_t1); (void)hipEventDestroy(p->ev_prep);
         (void)hipStreamDestroy(p->stream);
         if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
+        if (p->abort_stream) (void)hipStreamDestroy(p->abort_stream);
     }
 #endif
     free(p->chains_host); free(p->clu_dev); free(p->ref_sel); free(p->traj_dev); free(p->traj_cur);
@@ -996,7 +999,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         if (process_guard_acquire(device)) { free(p); return -1; }
         p->guarded = !share;
     }
-    if (hipStreamCreate(&p->stream) != hipSuccess || hipStreamCreate(&p->copy_stream) != hipSuccess) { if (p->guarded) process_guard_release(device); free(p); FAIL("hipStreamCreate failed"); }
+    if (hipStreamCreate(&p->stream) != hipSuccess || hipStreamCreate(&p->copy_stream) != hipSuccess || hipStreamCreate(&p->abort_stream) != hipSuccess) { if (p->guarded) process_guard_release(device); free(p); FAIL("hipStreamCreate failed"); }
     for (int i = 0; i < TASK_RING; i++) for (int k = 0; k < 3; k++) (void)hipEventCreate(&p->ev[i][k]);
     (void)hipEventCreate(&p->ev_t0); (void)hipEventCreate(&p->ev_t1); (void)hipEventCreate(&p->ev_prep);
 #endif
@@ -1903,9 +1906,11 @@ extern "C" int h264e_hip_stream_abort(h264e_hip_pool_t *p)
 #ifdef H264E_EMU
     *p->abort_dev = p->launch_counter;
 #else
-    /* the kernel polls a word in device memory: copy the request there on the copy stream, next to the running launch */
+    /* the kernel polls a word in device memory: the launch id is written there BY VALUE on a stream of its own, next to the running
+     * launch -- not behind the application's staging uploads on the copy stream (up to hundreds of MB), and not as a copy whose source
+     * could have moved on to the next launch's id by the time it executes */
     HIPCHK(hipSetDevice(p->device));
-    HIPCHK(hipMemcpyAsync(p->abort_dev, p->abort_word, sizeof(int), hipMemcpyHostToDevice, p->copy_stream));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)p->abort_dev, p->launch_counter, 1, p->abort_stream));
 #endif
     return 0;
 }

@@ -179,7 +179,9 @@ int  H264E_clip_encode_multi(H264E_clip_t **clips, int nclips, uint8_t **out, co
 void H264E_clip_rewind(H264E_clip_t *clip);
 /* resident input frames back to host memory (whole-clip residency only; bench.py's PCIe-inclusive measurement) */
 int  H264E_clip_download(H264E_clip_t *clip, int first, int nframes, uint8_t *i420);
-/* reconstruction (coded size, packed I420) of one of the last frames encoded (its picture slot must not have been reused) */
+/* reconstruction (coded size, packed I420) of one of the last frames encoded (its picture slot must not have been reused: the last
+ * ring - 1 frames in constant-QP mode; with rate control only the frames accepted since the last launch began -- the launches' hedge
+ * leaves are encoded over the pictures of older frames).  -1 outside that window. */
 int  H264E_clip_read_recon(H264E_clip_t *clip, int frame, uint8_t *dst);
 /* per encoded frame [3] sums of squared differences input vs reconstruction (Y, U, V), computed on the device: encode_app --psnr */
 void H264E_clip_set_ssd_output(H264E_clip_t *clip, uint64_t *ssd);
