@@ -53,16 +53,6 @@ struct RowTask
     mv32 clusters[2];
     const mv32 *clusters_per_mb;
 };
-#ifdef H264E_EMU
-template <class P> DEV P uniptr(P p) { return p; }
-#else
-template <class P> DEV P uniptr(P p)
-{
-    const unsigned long long v = (unsigned long long)(uintptr_t)p;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return (P)(uintptr_t)(((unsigned long long)hi << 32) | lo);
-}
-#endif
 DEV RowTask rowtask_load(const h264e_frame_task_t &T)
 {
     RowTask t;
@@ -137,18 +127,12 @@ DEV uint32_t ref_load4(const Plane &P, int x, int y)
 {
     y = imin(imax(y, 0), P.h - 1);
     const gu8 *r = P.p + (size_t)y*P.stride;
-#if !defined(H264E_EMU) && !H264E_COHERENT_LOADS
-    if (x >= 0 && x + 3 < P.w) return gload32(r + x);
-#endif
+    if (H264E_PLAIN_UNALIGNED_LOADS && x >= 0 && x + 3 < P.w) return gload32(r + x);
     if (x >= 0 && x + 7 < P.w)
     {
         /* unaligned 4 samples = two aligned coherent dwords + byte align (x + 7 < w keeps the second dword inside the row) */
         const uint64_t d = cload64x2(r + (x & ~3));
-#ifdef H264E_EMU
-        return (uint32_t)(d >> (8*(x & 3)));
-#else
-        return __builtin_amdgcn_alignbyte((uint32_t)(d >> 32), (uint32_t)d, x & 3);
-#endif
+        return alignbyte32((uint32_t)(d >> 32), (uint32_t)d, (unsigned)x & 3);
     }
     return ref_load4_border(r, P.w, x);
 }
@@ -159,13 +143,9 @@ DEV void lds32_store(uint8_t *p, uint32_t v) { memcpy(p, &v, 4); }
 /* 4 bytes at an arbitrary LDS byte address: two aligned dword reads + v_alignbyte */
 DEV uint32_t lds32u(const lu8 *p)
 {
-#ifdef H264E_EMU
-    uint32_t v; memcpy(&v, p, 4); return v;
-#else
-    const uint32_t a = (uint32_t)(uintptr_t)p;
-    const LDS_AS uint32_t *q = (const LDS_AS uint32_t *)(p - (a & 3));
-    return __builtin_amdgcn_alignbyte(q[1], q[0], a & 3);
-#endif
+    const unsigned a = (unsigned)(uintptr_t)p & 3;
+    const LDS_AS uint32_t *q = (const LDS_AS uint32_t *)(p - a);
+    return alignbyte32(ld32_aligned(q + 1), ld32_aligned(q), a);
 }
 
 /*
@@ -216,30 +196,25 @@ DEV bool rv_slice_last(const RefView &V, int Y)           /* is macroblock row Y
 /* one wait: row `drow` of the producing frame must have published `need` macroblocks */
 DEV void rv_wait_row(const RefView &V, int drow, int need)
 {
-#ifndef H264E_EMU
     const GLOBAL_AS int *flag = V.dep + drow;
     unsigned spins = 0;
     for (;;)
     {
-        const int seen = uni(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));      /* uni: scalar loop control */
+        const int seen = uni(dep_poll(flag));       /* uni: scalar loop control */
         if (seen >= need) break;
         /* negative = the producer stopped (abort / failure); bound expired = the producer never got there.  Either way the
          * samples behind this wait are not final: flag the row, which stops, poisons its counter and (for an expiry) raises the
          * launch's error flag right after this macroblock (h264e_kernels.hip) -- nothing encoded from them is ever returned */
         if (seen < 0) { if (V.fail) *V.fail = seen; break; }
         if (++spins > V.spin_limit) { if (V.fail) *V.fail = -1; break; }
-        __builtin_amdgcn_s_sleep(8);
+        wave_nap();
     }
-#else
-    (void)V; (void)drow; (void)need;
-#endif
 }
 /* sample rows y0..y1, columns up to x1.  Inside one slice the lowest macroblock row is the last to become final; row bands of
  * different slices advance independently, so every slice the rectangle touches is waited for at its lowest row inside it. */
 DEV void rv_wait_rect(const RefView &V, int y0, int x1, int y1)
 {
     if (V.far) *V.far += 1;
-#ifndef H264E_EMU
     if (!V.dep) return;
     const int X = imin(imax(x1, 0), V.P.w - 1) >> 4, Ya = imin(imax(y0, 0), V.P.h - 1) >> 4, Yb = imin(imax(y1, 0), V.P.h - 1) >> 4;
     const int need = imin(X + 2, V.nmbx);
@@ -250,9 +225,6 @@ DEV void rv_wait_rect(const RefView &V, int y0, int x1, int y1)
         else if (Y == Yb) rv_wait_row(V, Y + 1, need);
     }
     consumer_acquire();
-#else
-    (void)y0; (void)x1; (void)y1;
-#endif
 }
 
 /* The same wait inside a lane-group section (wave.h): rectangle and counters differ from group to group, so nothing here goes
@@ -260,7 +232,6 @@ DEV void rv_wait_rect(const RefView &V, int y0, int x1, int y1)
 DEV void rv_wait_rect_g(const RefView &V, int y0, int x1, int y1)
 {
     if (V.far) grp_count(V.far);
-#ifndef H264E_EMU
     if (!V.dep) return;
     const int X = imin(imax(x1, 0), V.P.w - 1) >> 4, Ya = imin(imax(y0, 0), V.P.h - 1) >> 4, Yb = imin(imax(y1, 0), V.P.h - 1) >> 4;
     const int need = imin(X + 2, V.nmbx);
@@ -272,17 +243,14 @@ DEV void rv_wait_rect_g(const RefView &V, int y0, int x1, int y1)
         unsigned spins = 0;
         for (;;)
         {
-            const int seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int seen = dep_poll(flag);
             if (seen >= need) break;
             if (seen < 0) { if (V.fail) *V.fail = seen; break; }
             if (++spins > V.spin_limit) { if (V.fail) *V.fail = -1; break; }
-            __builtin_amdgcn_s_sleep(8);
+            wave_nap();
         }
     }
     consumer_acquire();
-#else
-    (void)y0; (void)x1; (void)y1;
-#endif
 }
 
 /* one lane per window row: four 16-byte loads when the window's columns lie inside the picture (uniform test),
@@ -514,11 +482,7 @@ NOINLINE_DEV uint32_t interp4_hbm(const gu8 *p, int w, int h, int stride, int x,
 struct hp4_t { uint32_t x, y, z, w; };
 DEV int shr_opaque(int v, int s)
 {
-    int t = v >> s;
-#ifndef H264E_EMU
-    asm volatile("" : "+v"(t));
-#endif
-    return t;
+    return opaque_int(v >> s);
 }
 DEV hp4_t halfpel3_win(const lu8 *at, int ox, int oy)
 {
@@ -746,9 +710,9 @@ DEV uint32_t i4_pred_row(int m, int y, const uint8_t *edge, int dc, const uint16
  * predicts its row and takes its SAD.  Test order DC,V,DDL,VL,H,HU,DDR,HD,VR with a strict "<" keeps the
  * reference's tie-breaks.  top8 / leftcol (stride lstride) / tl point into the LDS working picture.
  * in = input block (stride 16), pred = LDS output (stride 16); returns mode | cost << 4.
- * scratch (LDS): edge[16] bytes, rows[36] dwords, rowsad[36] ints.
+ * scratch (LDS): edge[16] bytes + the prediction lookup table.
  */
-struct I4Scratch { uint8_t edge[16]; uint32_t rows[36]; int rowsad[36]; uint16_t lut[9*16]; };
+struct I4Scratch { uint8_t edge[16]; uint16_t lut[9*16]; };
 
 DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_t *top8, const uint8_t *leftcol, int lstride,
                        int mpred, int penalty, I4Scratch &S)
@@ -774,58 +738,27 @@ DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_
     }
     const int have_t = (avail & AV_T) != 0, have_l = (avail & AV_L) != 0, have_all = (avail & (AV_T | AV_L | AV_TL)) == (AV_T | AV_L | AV_TL);
     int best = 0, best_sad = 0;
-#ifdef H264E_EMU
-    WAVE_FOR(l)
     {
-        const int k = l >> 2, y = l & 3;
-        if (k < 9)
-        {
+        /* the rows and their SADs stay in registers (wave.h V64): lane 4k + y holds row y of mode slot k, the four row SADs of a slot
+         * are added inside the quad and read lane by lane -- no LDS round trips for the choice */
+        const V64 row = v64_make([&](int l) -> int {
+            const int k = l >> 2, y = l & 3;
+            if (k >= 9) return 0;
             const int m = k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 3 : k == 3 ? 7 : k == 4 ? 1 : k == 5 ? 8 : k == 6 ? 4 : k == 7 ? 6 : 5;
-            const uint32_t row = i4_pred_row(m, y, S.edge, dc, S.lut);
-            S.rows[l] = row;
-            S.rowsad[l] = (int)sad4_u8(lds32(in + 16*y), row, 0);
-        }
-    }
-    wave_sync();
-    for (int k = 0; k < 9; k++)
-    {
-        const int m = k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 3 : k == 3 ? 7 : k == 4 ? 1 : k == 5 ? 8 : k == 6 ? 4 : k == 7 ? 6 : 5;
-        const int ok = k == 0 ? 1 : k <= 3 ? have_t : k <= 5 ? have_l : have_all;
-        const int sad = S.rowsad[4*k] + S.rowsad[4*k + 1] + S.rowsad[4*k + 2] + S.rowsad[4*k + 3] + (m != mpred ? penalty : 0);
-        if (ok && (k == 0 || sad < best_sad)) { best = k; best_sad = sad; }
-    }
-    WAVE_FOR(l)
-    {
-        if (l < 4) lds32_store(pred + 16*l, S.rows[4*best + l]);
-    }
-    wave_sync();
-#else
-    {
-        /* same computation with the rows and their SADs kept in registers: lane 4k + y holds row y of mode slot k, the four
-         * row SADs of a slot are added inside the quad (DPP) and read with v_readlane -- no LDS round trips for the choice */
-        const int l = LANE, k = l >> 2, y = l & 3;
-        uint32_t row = 0;
-        int qs = 0;
-        if (k < 9)
-        {
-            const int m = k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 3 : k == 3 ? 7 : k == 4 ? 1 : k == 5 ? 8 : k == 6 ? 4 : k == 7 ? 6 : 5;
-            row = i4_pred_row(m, y, S.edge, dc, S.lut);
-            qs = (int)sad4_u8(lds32(in + 16*y), row, 0);
-        }
-        qs += __builtin_amdgcn_update_dpp(0, qs, 0xB1, 0xf, 0xf, true);      /* quad_perm [1,0,3,2] */
-        qs += __builtin_amdgcn_update_dpp(0, qs, 0x4E, 0xf, 0xf, true);      /* quad_perm [2,3,0,1] */
+            return (int)i4_pred_row(m, y, S.edge, dc, S.lut);
+        });
+        const V64 qs = v64_quad_sum(v64_map(row, [&](int l, int r) -> int { return (l >> 2) < 9 ? (int)sad4_u8(lds32(in + 16*(l & 3)), (uint32_t)r, 0) : 0; }));
 #pragma unroll
         for (int kk = 0; kk < 9; kk++)
         {
             const int m = kk == 0 ? 2 : kk == 1 ? 0 : kk == 2 ? 3 : kk == 3 ? 7 : kk == 4 ? 1 : kk == 5 ? 8 : kk == 6 ? 4 : kk == 7 ? 6 : 5;
             const int ok = kk == 0 ? 1 : kk <= 3 ? have_t : kk <= 5 ? have_l : have_all;
-            const int sad = __builtin_amdgcn_readlane(qs, 4*kk) + (m != mpred ? penalty : 0);
+            const int sad = v64_read(qs, 4*kk) + (m != mpred ? penalty : 0);
             if (ok && (kk == 0 || sad < best_sad)) { best = kk; best_sad = sad; }
         }
-        if (k == best) lds32_store(pred + 16*y, row);
+        v64_each(row, [&](int l, int r) { if ((l >> 2) == best) lds32_store(pred + 16*(l & 3), (uint32_t)r); });
         wave_sync();
     }
-#endif
     const int bm = best == 0 ? 2 : best == 1 ? 0 : best == 2 ? 3 : best == 3 ? 7 : best == 4 ? 1 : best == 5 ? 8 : best == 6 ? 4 : best == 7 ? 6 : 5;
     return bm + (best_sad << 4);
 }
@@ -1093,33 +1026,12 @@ DEV void bw_put_tab(BitW &b, uint16_t e) { bw_put(b, (int)(e & 255), (uint32_t)(
 DEV int cavlc_block(BitW &b, const CavlcTab &ct, const int16_t *base, int first, int maxn, int nctx)
 {
     first = uni(first); maxn = uni(maxn); nctx = uni(nctx);
-    uint32_t mask = 0;
-#ifdef H264E_EMU
-    {
-        const uint32_t *w = (const uint32_t *)base;
-        const int nw = (first + maxn + 1) >> 1;
-        for (int k = 0; k < 8; k++)
-            if (k < nw)
-            {
-                const uint32_t v = w[k];
-                if (v & 0xffffu) mask |= 1u << (2*k);
-                if (v >> 16) mask |= 2u << (2*k);
-            }
-        mask = (mask >> first) & ((1u << maxn) - 1);
-    }
-#define COEF(p) ((int)base[first + (p)])
-#else
-    /* one LDS read for the whole block: lane p holds coefficient p; the scalar code below picks coefficients with
-     * v_readlane instead of one LDS round trip each */
-    const int cv = LANE < maxn ? (int)base[first + LANE] : 0;
-    mask = (uint32_t)__ballot(cv != 0);
-#define COEF(p) __builtin_amdgcn_readlane(cv, (p))
-#endif
-#ifdef H264E_EMU
-    const int total = __builtin_popcount(mask);
-#else
-    const int total = __popc(mask);
-#endif
+    /* one LDS read for the whole block: lane p holds coefficient p (wave.h V64); the scalar code below picks coefficients lane by lane
+     * instead of one LDS round trip each */
+    const V64 cv = v64_make([&](int l) -> int { return l < maxn ? (int)base[first + l] : 0; });
+    const uint32_t mask = (uint32_t)v64_nonzero_ballot(cv);
+#define COEF(p) v64_read(cv, (p))
+    const int total = popc32(mask);
     /* trailing ones: up to three leading (highest position) coefficients of magnitude 1 */
     int t1 = 0;
     uint32_t t1sign = 0;

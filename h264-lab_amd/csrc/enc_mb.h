@@ -537,9 +537,7 @@ template <class SIG> DEV void inter_choose(RowLds &L, MbBuf &B, MbCtx &m, SIG si
     int sad, sad_skip = 0x7FFFFFFF, sad_best = 0x7FFFFFFF, cand_cost_best = 0, j = 0, ncand = 0, sad4[4];
     mv32 mv_best = MV_NA;
     LaneArr cand;                           /* start candidates (H:5360-5386), register resident */
-#ifndef H264E_EMU
-    cand.r = 0;
-#endif
+    cand.clear();
 
     /* H:3877-3890 skip predictor */
     const mv32 mv_pred16 = mvp_get(L, B, m, 0, 0, 4, 4);

@@ -76,13 +76,9 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
     L.qconst[3] = k_skip_thr_i4x4[T.qp]; L.qconst[4] = k_lambda_i4_q4[T.qp]; L.qconst[5] = k_lambda_i16_q4[T.qp];
     for (int i = 0; i < 32; i++) L.prof[0][i] = L.prof[1][i] = 0;
     L.prof_last[0] = L.prof_last[1] = 0;
-#if defined(H264E_STAMPS) && !defined(H264E_EMU)
-    L.prof_c0 = __builtin_readcyclecounter(); L.prof_w0 = wall_clock64();      /* shader-clock cycles vs constant 100 MHz clock: effective frequency */
-#endif
+    PROF_ROW_BEGIN(L);
     wave_sync();
-#if defined(H264E_STAMPS) && !defined(H264E_EMU)
-    L.prof_last[0] = L.prof_last[1] = __builtin_readcyclecounter();
-#endif
+    PROF_ROW_SYNC(L);
 }
 
 /* neighbour record of the macroblock above -> LDS (h264-lab.h:742-745 contexts, :590-606 deblock state): 16 coherent dword
@@ -465,22 +461,14 @@ DEV void row_end(RowLds &L, const h264e_geom_t &G, const ChainG &C, int row)
     gu8 *M = (gu8 *)(C.rowmeta + row);       /* {nbits, lead_skips, trail_skips, overflow}: read by the finalizer workgroup */
     if (wave_lane() == 0)
     {
-#ifdef H264E_EMU
-        *C.far_reads += L.far_reads[0] + L.far_reads[1];
-#else
-        if (L.far_reads[0] + L.far_reads[1]) __hip_atomic_fetch_add(C.far_reads, L.far_reads[0] + L.far_reads[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+        g_atomic_add(C.far_reads, L.far_reads[0] + L.far_reads[1]);
         cstore32(M, nbits);
         cstore32(M + 4, (uint32_t)(L.coded_any ? L.lead_skips : G.nmbx));
         cstore32(M + 8, (uint32_t)(L.coded_any ? L.skip_run : 0));
         cstore32(M + 12, (uint32_t)bw.overflow);
     }
     wave_sync();
-#if defined(H264E_STAMPS) && !defined(H264E_EMU)
-    L.prof[PROF_W][28] = __builtin_readcyclecounter() - L.prof_c0; L.prof[PROF_W][29] = wall_clock64() - L.prof_w0;
-    wave_sync();
-    if (LANE < 32 && C.prof) atomicAdd(C.prof + LANE, L.prof[PROF_W][LANE]);
-#endif
+    PROF_ROW_END(L, C);
 }
 
 /* ------------------------------------------------------------------ slice splice (one wavefront per chain) */
@@ -570,12 +558,8 @@ DEV int device_clusters_walk(const h264e_geom_t &G, const h264e_frame_task_t &T,
         for (int base = k0; base < k1; base += 64)
         {
             int start = 0;
-#ifdef H264E_EMU
-            mv32 mine0[64], mine1[64];
-            for (int l = 0; l < 64; l++) { mine0[l] = s[0]; mine1[l] = s[1]; }
-#else
-            mv32 mine0 = s[0], mine1 = s[1];
-#endif
+            /* the state in front of every macroblock of the batch, one per lane (wave.h V64) */
+            V64 mine0 = v64_make([&](int) -> int { return s[0]; }), mine1 = v64_make([&](int) -> int { return s[1]; });
             for (;;)
             {
                 const mv32 c0 = s[0], c1 = s[1];
@@ -610,27 +594,14 @@ DEV int device_clusters_walk(const h264e_geom_t &G, const h264e_frame_task_t &T,
                 if (rec[ke].type < 5) clusters_step(s, rec[ke].mv0);
                 s[0] = (mv32)uni(s[0]); s[1] = (mv32)uni(s[1]); first_bad = uni(first_bad);
                 start = e + 1;
-                WAVE_FOR(l)
-                {
-#ifdef H264E_EMU
-                    if (l >= start) { mine0[l] = s[0]; mine1[l] = s[1]; }
-#else
-                    if (l >= start) { mine0 = s[0]; mine1 = s[1]; }
-#endif
-                }
+                mine0 = v64_map(mine0, [&](int l, int v) -> int { return l >= start ? s[0] : v; });
+                mine1 = v64_map(mine1, [&](int l, int v) -> int { return l >= start ? s[1] : v; });
                 if (start >= 64) break;
             }
             if (traj)
             {
-                WAVE_FOR(l)
-                {
-                    const int k = base + l;
-#ifdef H264E_EMU
-                    if (k < k1) { traj[2*k] = mine0[l]; traj[2*k + 1] = mine1[l]; }
-#else
-                    if (k < k1) { traj[2*k] = mine0; traj[2*k + 1] = mine1; }
-#endif
-                }
+                v64_each(mine0, [&](int l, int v) { const int k = base + l; if (k < k1) traj[2*k] = v; });
+                v64_each(mine1, [&](int l, int v) { const int k = base + l; if (k < k1) traj[2*k + 1] = v; });
             }
         }
     }
@@ -709,12 +680,8 @@ DEV void finalize_frame(const h264e_geom_t &G, const ChainG &C, const h264e_fram
     F.all_skipped = all_skipped;
     F.clusters_moved = moved;
     F.overflow = overflow | s.overflow;
-#ifdef H264E_EMU
-    F.far_reads = *C.far_reads; *C.far_reads = 0;
-#else
-    F.far_reads = __hip_atomic_load(C.far_reads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wave_lane() == 0) __hip_atomic_store(C.far_reads, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+    F.far_reads = g_atomic_load(C.far_reads);
+    if (wave_lane() == 0) g_atomic_store(C.far_reads, 0);
     *C.cursor = start + ((nbytes + 15u) & ~15u);
     stepflags[0] = moved;
     stepflags[1] = overflow | s.overflow;
@@ -784,10 +751,8 @@ DEV uint32_t nal_escape_copy(GLOBAL_AS uint8_t *dst, uint32_t cap, const GLOBAL_
                     dst[j++] = b;
                 }
             }
-#ifndef H264E_EMU
-            esc = (uint32_t)__builtin_amdgcn_readfirstlane((int)esc);       /* lane 0 ran the automaton: its counters are the wave's */
-            cntz = __builtin_amdgcn_readfirstlane(cntz);
-#endif
+            esc = (uint32_t)uni((int)esc);       /* lane 0 ran the automaton: its counters are the wave's */
+            cntz = uni(cntz);
         }
         wave_sync();
     }
@@ -819,9 +784,7 @@ DEV void export_frame(const h264e_geom_t &G, const ChainG &C, const h264e_frame_
     in_device = doff > T.host_rbsp_cap;
     if (!in_device)
     {
-#ifndef H264E_EMU
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        /* the NAL arena was written by this wave just now */
-#endif
+        drain_stores();                          /* the NAL arena was written by this wave just now */
         wave_sync();
         const uint32_t nw = (doff + 15u) >> 4;
         const GLOBAL_AS u32x4 *src = (const GLOBAL_AS u32x4 *)C.nal_arena;

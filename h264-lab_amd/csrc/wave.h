@@ -20,6 +20,10 @@
 
 /* explicit address spaces: HBM pointers that were loaded from memory would otherwise be generic (FLAT instructions) */
 #ifdef H264E_EMU
+/* the emulation cannot type-check address spaces (GLOBAL_AS / LDS_AS are empty here), so it checks them at run time: every accessor of
+ * memory that other workgroups or the host see asserts that the address lies in a block the "device" allocated (tests/emu/emu_backend.cpp) */
+extern "C" void emu_check_global(const void *p, size_t n, const char *file, int line);
+#define EMU_GLOBAL(p, n) emu_check_global((const void *)(p), (n), __FILE__, __LINE__)
 #define GLOBAL_AS
 #define LDS_AS
 #define NOINLINE_DEV static __attribute__((noinline))
@@ -142,9 +146,36 @@ DEV V16 v16_from(const V16 &a, const V16 &idx) { V16 r; for (int i = 0; i < 16; 
 DEV unsigned v16_nonzero_mask(const V16 &a) { unsigned m = 0; for (int i = 0; i < 16; i++) if (a.v[i]) m |= 1u << i; return m; }
 #define V16_TILES 1
 
+/* ---- small primitives with one definition per build (the kernel headers use these instead of switching on the build themselves) */
+template <class P> DEV P uniptr(P p) { return p; }
+DEV uint32_t alignbyte32(uint32_t hi, uint32_t lo, unsigned sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8*(sh & 3))); }
+DEV uint32_t ld32_aligned(const void *q) { uint32_t v; memcpy(&v, q, 4); return v; }
+DEV int opaque_int(int v) { return v; }
+DEV int popc32(uint32_t v) { return __builtin_popcount(v); }
+/* a progress counter of another workgroup: the emulation runs producers to completion before their consumers, so it is always there */
+DEV int dep_poll(const int *p) { EMU_GLOBAL(p, 4); return 0x7fffffff; }
+DEV void wave_nap() {}
+DEV void consumer_acquire() {}
+DEV void drain_stores() {}
+DEV void g_atomic_add(int *p, int v) { EMU_GLOBAL(p, 4); *p += v; }
+DEV int g_atomic_load(const int *p) { EMU_GLOBAL(p, 4); return *p; }
+DEV void g_atomic_store(int *p, int v) { EMU_GLOBAL(p, 4); *p = v; }
+/* V64: one value per lane of the wavefront that lives ACROSS lane sections (a register on the device; the emulation keeps the array) */
+struct V64 { int v[64]; };
+template <class F> DEV V64 v64_make(F f) { V64 r; WAVE_FOR(l) r.v[l] = f(l); return r; }
+template <class F> DEV V64 v64_map(const V64 &a, F f) { V64 r; WAVE_FOR(l) r.v[l] = f(l, a.v[l]); return r; }
+template <class F> DEV void v64_each(const V64 &a, F f) { WAVE_FOR(l) f(l, a.v[l]); }
+DEV V64 v64_quad_sum(const V64 &a) { V64 r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l & ~3] + a.v[(l & ~3) + 1] + a.v[(l & ~3) + 2] + a.v[(l & ~3) + 3]; return r; }
+DEV int v64_read(const V64 &a, int lane) { return a.v[lane]; }
+DEV uint64_t v64_nonzero_ballot(const V64 &a) { uint64_t m = 0; for (int l = 0; l < 64; l++) if (a.v[l]) m |= 1ull << l; return m; }
+#define PROF_ROW_BEGIN(L) do { } while (0)
+#define PROF_ROW_SYNC(L) do { } while (0)
+#define PROF_ROW_END(L, C) do { } while (0)
+
 #else /* device build */
 
 #include <hip/hip_runtime.h>
+#define EMU_GLOBAL(p, n) do { } while (0)
 /* lane of the wavefront: a workgroup is ONE wavefront (64 threads) or, in the two-wave pipeline, two wavefronts with different jobs */
 /* OPAQUE to the optimiser on purpose: with a plain expression the compiler computes every lane-dependent LDS address of the macroblock
  * loop once, in front of the loop, and keeps the lot alive in registers across the whole loop body (measured: two-wave kernel 168 VGPRs +
@@ -305,6 +336,40 @@ DEV V16 v16_from(const V16 &a, const V16 &idx)
 DEV unsigned long long v16_nonzero_ballot(const V16 &a) { return __ballot(a.v != 0); }
 DEV unsigned v16_nonzero_mask(const V16 &a) { return (unsigned)(__ballot(a.v != 0) & 0xffffu); }
 #define V16_TILES 4
+
+/* ---- small primitives with one definition per build (the kernel headers use these instead of switching on the build themselves) */
+template <class P> DEV P uniptr(P p)
+{
+    const unsigned long long v = (unsigned long long)(uintptr_t)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (P)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+DEV uint32_t alignbyte32(uint32_t hi, uint32_t lo, unsigned sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+DEV uint32_t ld32_aligned(const LDS_AS uint32_t *q) { return *q; }
+/* keeps the compiler from looking through a value (enc_kernels.h shr_opaque: the v_ashr_pk_u8_i32 finding) */
+DEV int opaque_int(int v) { asm volatile("" : "+v"(v)); return v; }
+DEV int popc32(uint32_t v) { return __popc(v); }
+/* a progress counter of another workgroup, read past the caches' stale copies (relaxed, agent scope: an sc1 load) */
+DEV int dep_poll(const GLOBAL_AS int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void wave_nap() { __builtin_amdgcn_s_sleep(8); }
+DEV void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+DEV void g_atomic_add(GLOBAL_AS int *p, int v) { if (v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV int g_atomic_load(const GLOBAL_AS int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void g_atomic_store(GLOBAL_AS int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+/* V64: one value per lane of the wavefront that lives ACROSS lane sections: a register */
+struct V64 { int v; };
+template <class F> DEV V64 v64_make(F f) { V64 r; r.v = f(LANE); return r; }
+template <class F> DEV V64 v64_map(const V64 &a, F f) { V64 r; r.v = f(LANE, a.v); return r; }
+template <class F> DEV void v64_each(const V64 &a, F f) { f(LANE, a.v); }
+DEV V64 v64_quad_sum(const V64 &a)
+{
+    V64 r;
+    r.v = a.v + __builtin_amdgcn_update_dpp(0, a.v, 0xB1, 0xf, 0xf, true);      /* quad_perm [1,0,3,2] */
+    r.v += __builtin_amdgcn_update_dpp(0, r.v, 0x4E, 0xf, 0xf, true);           /* quad_perm [2,3,0,1] */
+    return r;
+}
+DEV int v64_read(const V64 &a, int lane) { return __builtin_amdgcn_readlane(a.v, lane); }
+DEV uint64_t v64_nonzero_ballot(const V64 &a) { return __ballot(a.v != 0); }
 #endif
 
 /* diagnostic build only (-DH264E_STAMPS): cycle stamps per pipeline phase, accumulated in LDS (never in the product) */
@@ -314,11 +379,20 @@ DEV unsigned v16_nonzero_mask(const V16 &a) { return (unsigned)(__ballot(a.v != 
 #define PCOUNT(L, id) do { (L).prof[PROF_W][id]++; } while (0)
 #define PTIC() unsigned long long tic_ = __builtin_readcyclecounter()
 #define PTOC(L, id) do { (L).prof[PROF_W][id] += __builtin_readcyclecounter() - tic_; } while (0)
+#define PROF_ROW_BEGIN(L) do { (L).prof_c0 = __builtin_readcyclecounter(); (L).prof_w0 = wall_clock64(); } while (0)     /* shader-clock cycles vs constant 100 MHz clock: effective frequency */
+#define PROF_ROW_SYNC(L) do { (L).prof_last[0] = (L).prof_last[1] = __builtin_readcyclecounter(); } while (0)
+#define PROF_ROW_END(L, C) do { (L).prof[PROF_W][28] = __builtin_readcyclecounter() - (L).prof_c0; (L).prof[PROF_W][29] = wall_clock64() - (L).prof_w0; wave_sync(); \
+                                if (LANE < 32 && (C).prof) atomicAdd((C).prof + LANE, (L).prof[PROF_W][LANE]); } while (0)
 #else
 #define STAMP(L, id) do { } while (0)
 #define PCOUNT(L, id) do { } while (0)
 #define PTIC() do { } while (0)
 #define PTOC(L, id) do { } while (0)
+#ifndef PROF_ROW_BEGIN
+#define PROF_ROW_BEGIN(L) do { } while (0)
+#define PROF_ROW_SYNC(L) do { } while (0)
+#define PROF_ROW_END(L, C) do { } while (0)
+#endif
 #endif
 
 /*
@@ -330,11 +404,13 @@ struct LaneArr
 {
 #ifdef H264E_EMU
     int a[64];
+    void clear() { for (int i = 0; i < 64; i++) a[i] = 0; }
     int get(int i) const { return a[i]; }
     void set(int i, int v) { a[i] = v; }
     int has(int v, int n) const { for (int i = 0; i < n; i++) if (a[i] == v) return 1; return 0; }     /* is v among the first n elements? */
 #else
     int r;
+    __device__ __forceinline__ void clear() { r = 0; }
     __device__ __forceinline__ int get(int i) const { return __builtin_amdgcn_readlane(r, __builtin_amdgcn_readfirstlane(i)); }
     __device__ __forceinline__ void set(int i, int v) { r = (LANE == __builtin_amdgcn_readfirstlane(i)) ? __builtin_amdgcn_readfirstlane(v) : r; }    /* compare + select: no v_writelane builtin */
     __device__ __forceinline__ int has(int v, int n) const { return __ballot(LANE < n && r == __builtin_amdgcn_readfirstlane(v)) != 0; }
@@ -346,8 +422,8 @@ typedef GLOBAL_AS uint8_t gu8;                        /* a byte in HBM */
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef GLOBAL_AS u32_unaligned gu32u;
 
-DEV uint32_t gload32(const gu8 *p) { return *(const gu32u *)p; }
-DEV void gstore32(gu8 *p, uint32_t v) { *(gu32u *)p = v; }
+DEV uint32_t gload32(const gu8 *p) { EMU_GLOBAL(p, 4); return *(const gu32u *)p; }
+DEV void gstore32(gu8 *p, uint32_t v) { EMU_GLOBAL(p, 4); *(gu32u *)p = v; }
 
 /*
  * Coherent accessors for every byte that one workgroup writes and another reads INSIDE a launch (pictures, neighbour
@@ -357,16 +433,19 @@ DEV void gstore32(gu8 *p, uint32_t v) { *(gu32u *)p = v; }
  * loads (MI355X_MICROARCH.md "Valid forms").  Naturally aligned 4- or 8-byte accesses only.
  */
 #ifdef H264E_EMU
-DEV uint32_t cload32(const gu8 *p) { uint32_t v; memcpy(&v, p, 4); return v; }
-DEV uint64_t cload64(const gu8 *p) { uint64_t v; memcpy(&v, p, 8); return v; }
-DEV void cstore32(gu8 *p, uint32_t v) { memcpy(p, &v, 4); }
-DEV void cstore64(gu8 *p, uint64_t v) { memcpy(p, &v, 8); }
+#define H264E_PLAIN_UNALIGNED_LOADS 0
+DEV uint32_t cload32(const gu8 *p) { uint32_t v; EMU_GLOBAL(p, 4); memcpy(&v, p, 4); return v; }
+DEV uint64_t cload64(const gu8 *p) { uint64_t v; EMU_GLOBAL(p, 8); memcpy(&v, p, 8); return v; }
+DEV void cstore32(gu8 *p, uint32_t v) { EMU_GLOBAL(p, 4); memcpy(p, &v, 4); }
+DEV void cstore64(gu8 *p, uint64_t v) { EMU_GLOBAL(p, 8); memcpy(p, &v, 8); }
 #else
 /* H264E_COHERENT_LOADS = 1: sc1 loads, the consumer needs no acquire.  0: plain loads behind ONE agent-scope acquire per
  * hand-off (invalidates the CU's L1), the form cdna_hip_programming.md Guideline 16 recommends with write-through stores. */
 #ifndef H264E_COHERENT_LOADS
 #define H264E_COHERENT_LOADS 0
 #endif
+/* plain (cached) loads may be unaligned dword loads; the coherent sc1 form needs natural alignment (enc_kernels.h ref_load4) */
+#define H264E_PLAIN_UNALIGNED_LOADS (!H264E_COHERENT_LOADS)
 #if H264E_COHERENT_LOADS
 DEV uint32_t cload32(const gu8 *p) { return __hip_atomic_load((const GLOBAL_AS uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV uint64_t cload64(const gu8 *p) { return __hip_atomic_load((const GLOBAL_AS uint64_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -251,3 +251,14 @@ def test_encode_multi_equals_separate_encodes():
         e.close()
     for (out, sizes, st), (wbytes, wsizes) in zip(res, want):
         assert out == wbytes and sizes == wsizes
+
+
+def test_emulation_refuses_non_device_addresses_in_global_accessors():
+    """the tripwire for the address-space lesson of round 2 (a pointer to a register copy cast to a global pointer: a GPU memory fault the
+    emulation could not see): every global-memory accessor of the kernel sources (wave.h cload / cstore / gload / dep_poll / g_atomic_*)
+    checks in the emulation that its address lies in a block the emulated device allocated, and aborts with file:line otherwise"""
+    import sys
+    code = ("import ctypes as C; L = C.CDLL(%r); b = C.create_string_buffer(64); "
+            "L.emu_check_global.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_int]; L.emu_check_global(C.addressof(b), 4, b'probe.h', 7)") % pkg.EMU_LIB
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode != 0 and "probe.h:7" in r.stderr and "not device memory" in r.stderr
