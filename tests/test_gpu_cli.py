@@ -98,7 +98,7 @@ def test_cli_clip_pipeline_full_length(app, tmp_path, name, extra):
 
 def test_cli_4k_file_bounded_host_memory(app, tmp_path):
     """a 4K file through --clip 1 with the default budgets: output equals the reference's stream, and the process stays under
-    2 GB of resident host memory (two pinned staging buffers + one output buffer, whatever the length of the file)"""
+    2.5 GB of resident host memory (two pinned staging buffers, one output buffer, the slot ring's result mirrors: budgets, not file sizes)"""
     g = GOLDEN_BIG["4k_30"]
     yuv = _synth_file(tmp_path, g["w"], g["h"], g["frames"])
     out = tmp_path / "o.264"
@@ -115,7 +115,9 @@ def test_cli_4k_file_bounded_host_memory(app, tmp_path):
     assert r.returncode == 0 and tail and tail[-1].endswith("RC=0"), text
     assert hashlib.md5(out.read_bytes()).hexdigest() == g["md5"]
     rss_kb = int(tail[-1].split()[0].split("=")[1])
-    assert rss_kb < 2 * 1024 * 1024, (rss_kb, text)
+    # 2 x 384 MB staging + 64 MB output + <= 896 MB of host-mapped result mirrors (the slot ring's budget) + the HIP runtime itself
+    # (code objects, three streams, signal pools: ~0.3 GB): about 2.1 GB whatever the length of the file
+    assert rss_kb < 2.5 * 1024 * 1024, (rss_kb, text)
 
 
 def test_cli_psnr_clip_mode_equals_frame_mode(app, tmp_path):
