@@ -122,13 +122,17 @@ DEV void load_top(RowLds &L, MbBuf &B, const h264e_geom_t &G, const GLOBAL_AS h2
 /* h264-lab.h:5731-5740 + 3536-3562: input macroblock -> LDS, replicating the last valid column / row of cropped pictures */
 DEV void load_input(MbBuf &B, const h264e_geom_t &G, const RowTask &T, int mbx, int mby)
 {
+    /* a macroblock that lies inside the picture (all but the last column / row of a cropped picture) is 96 dword loads; only the
+     * cropped edge replicates sample by sample */
+    const bool inside = (mbx + 1)*16 <= G.width && (mby + 1)*16 <= G.height;
     WAVE_FOR(l)
     {
         {
             int r = l >> 2, c = l & 3, yy = imin(mby*16 + r, G.height - 1);
             const gu8 *p = (const gu8 *)T.in[0] + (size_t)yy*T.in_stride[0];
             uint32_t v = 0;
-            for (int k = 0; k < 4; k++) v |= (uint32_t)p[imin(mbx*16 + 4*c + k, G.width - 1)] << (8*k);
+            if (inside) v = gload32(p + mbx*16 + 4*c);
+            else for (int k = 0; k < 4; k++) v |= (uint32_t)p[imin(mbx*16 + 4*c + k, G.width - 1)] << (8*k);
             lds32_store(B.inp + 16*r + 4*c, v);
         }
         if (l < 32)
@@ -137,7 +141,8 @@ DEV void load_input(MbBuf &B, const h264e_geom_t &G, const RowTask &T, int mbx, 
             /* (selected, not indexed: a lane-varying index would put the task copy into scratch memory) */
             const gu8 *p = (const gu8 *)(pl ? T.in[2] : T.in[1]) + (size_t)yy*(pl ? T.in_stride[2] : T.in_stride[1]);
             uint32_t v = 0;
-            for (int k = 0; k < 4; k++) v |= (uint32_t)p[imin(mbx*8 + 4*c + k, G.width/2 - 1)] << (8*k);
+            if (inside) v = gload32(p + mbx*8 + 4*c);
+            else for (int k = 0; k < 4; k++) v |= (uint32_t)p[imin(mbx*8 + 4*c + k, G.width/2 - 1)] << (8*k);
             lds32_store(B.inp_c + 16*r + 8*pl + 4*c, v);
         }
     }
