@@ -690,14 +690,14 @@ DEV void wave_pred_chroma(uint8_t *dst, const uint8_t *left, const uint8_t *top,
  * edge (LDS) holds the 13 neighbours along the block border: edge[4 + i] = sample i steps clockwise from the
  * top-left corner (i = -4..-1 left column bottom-up, 0 corner, 1..8 top row incl. top-right).
  */
-DEV uint32_t i4_pred_row(int m, int y, const uint8_t *edge, int dc, const uint16_t *lut /* LDS copy of k_i4_lut */)
+DEV uint32_t i4_pred_row(int m, const uint8_t *edge, int dc, uint32_t lut01, uint32_t lut23 /* the row's four k_i4_lut entries, two per word */)
 {
     if (m == 2) return (uint32_t)dc*0x01010101u;
     uint32_t o = 0;
 #pragma unroll
     for (int x = 0; x < 4; x++)
     {
-        const uint32_t e = lut[16*m + 4*y + x];
+        const uint32_t e = ((x < 2 ? lut01 : lut23) >> (16*(x & 1))) & 0xffffu;
         const int t = (int)(e & 3), a = edge[(e >> 2) & 15], b = edge[(e >> 6) & 15], c = edge[(e >> 10) & 15];
         const int v = t == 0 ? (a + 2*b + c + 2) >> 2 : t == 1 ? (a + b + 1) >> 1 : t == 2 ? a : (a + 3*b + 2) >> 2;
         o |= (uint32_t)v << (8*x);
@@ -710,12 +710,23 @@ DEV uint32_t i4_pred_row(int m, int y, const uint8_t *edge, int dc, const uint16
  * predicts its row and takes its SAD.  Test order DC,V,DDL,VL,H,HU,DDR,HD,VR with a strict "<" keeps the
  * reference's tie-breaks.  top8 / leftcol (stride lstride) / tl point into the LDS working picture.
  * in = input block (stride 16), pred = LDS output (stride 16); returns mode | cost << 4.
- * scratch (LDS): edge[16] bytes + the prediction lookup table.
+ * scratch (LDS): edge[16] bytes + the prediction lookup table; lut01 / lut23 (i4_lut_lanes): every lane's own four table entries,
+ * which never change (lane = mode slot, row), fetched once per macroblock instead of once per sample.
  */
 struct I4Scratch { uint8_t edge[16]; uint16_t lut[9*16]; };
 
+/* lane 4k + y -> the table entries of mode slot k, row y: samples 0,1 (which = 0) or 2,3 (which = 1), 16 bits each */
+DEV V64 i4_lut_lanes(const I4Scratch &S, int which)
+{
+    return v64_make([&](int l) -> int {
+        const int k = l >> 2, y = l & 3;
+        if (k >= 9) return 0;
+        const int m = k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 3 : k == 3 ? 7 : k == 4 ? 1 : k == 5 ? 8 : k == 6 ? 4 : k == 7 ? 6 : 5;
+        return (int)((uint32_t)S.lut[16*m + 4*y + 2*which] | ((uint32_t)S.lut[16*m + 4*y + 2*which + 1] << 16));
+    });
+}
 DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_t *top8, const uint8_t *leftcol, int lstride,
-                       int mpred, int penalty, I4Scratch &S)
+                       int mpred, int penalty, I4Scratch &S, const V64 &lut01, const V64 &lut23)
 {
     WAVE_FOR(l)
     {
@@ -741,11 +752,11 @@ DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_
     {
         /* the rows and their SADs stay in registers (wave.h V64): lane 4k + y holds row y of mode slot k, the four row SADs of a slot
          * are added inside the quad and read lane by lane -- no LDS round trips for the choice */
-        const V64 row = v64_make([&](int l) -> int {
-            const int k = l >> 2, y = l & 3;
+        const V64 row = v64_map(lut01, [&](int l, int e01) -> int {
+            const int k = l >> 2;
             if (k >= 9) return 0;
             const int m = k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 3 : k == 3 ? 7 : k == 4 ? 1 : k == 5 ? 8 : k == 6 ? 4 : k == 7 ? 6 : 5;
-            return (int)i4_pred_row(m, y, S.edge, dc, S.lut);
+            return (int)i4_pred_row(m, S.edge, dc, (uint32_t)e01, (uint32_t)v64_own(lut23, l));
         });
         const V64 qs = v64_quad_sum(v64_map(row, [&](int l, int r) -> int { return (l >> 2) < 9 ? (int)sad4_u8(lds32(in + 16*(l & 3)), (uint32_t)r, 0) : 0; }));
 #pragma unroll

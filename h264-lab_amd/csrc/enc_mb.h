@@ -236,7 +236,6 @@ DEV int diamond_g(RowLds &L, const MbBuf &B, const MbCtx &m, int px, int py, mv3
     int dir, cloop, dir_prev, cost;
     mv32 v;
     const int g = w >> 2, npass = (g*h) >> 4;
-    PCOUNT(L, 18);
     for (;;)
     {
         dir = 0; cloop = 4; dir_prev = -1;
@@ -247,12 +246,10 @@ DEV int diamond_g(RowLds &L, const MbBuf &B, const MbCtx &m, int px, int py, mv3
         do
         {
             v = mvadd(mv, mvmk(DX(dir), DY(dir)));
-            PCOUNT(L, 19);
             if (in_rect(v, range) && CGET(cur, dir) == 0xffffu)
             {
                 if (!(have & (1 << dir)))
                 {
-                    PCOUNT(L, 17);
                     int want = 0, s4[4];
 #pragma unroll
                     for (int d = 0; d < 4; d++)
@@ -711,6 +708,7 @@ template <class BOUND> DEV int intra4_choose(RowLds &L, MbBuf &B, const MbCtx &m
     int cost = m.lambda_i4;
     unsigned nz_mask = 0;
     if (cost >= bound()) return I4_LOST;
+    const V64 lut01 = i4_lut_lanes(L.i4s, 0), lut23 = i4_lut_lanes(L.i4s, 1);      /* every lane's own prediction-table entries, for all 16 blocks */
     WAVE_FOR(l)
     {
         if (l < 16) { r0[-24 + l] = B.pix_top[l]; r0[24*l - 1] = L.pix_left[l]; }
@@ -731,7 +729,9 @@ template <class BOUND> DEV int intra4_choose(RowLds &L, MbBuf &B, const MbCtx &m
         if (n < 3 && (avail & AV_T)) a |= AV_TR;
         int mpred = imin(L.i4_left[r], B.i4_top[c]);
         if (mpred < 0) mpred = 2;
-        int res = wave_i4_choose(bin, pr, a, blk - 24, blk - 1, 24, mpred, MUL_LAMBDA(3, m.lambda_q4), L.i4s);
+        STAMP(L, 19);
+        int res = wave_i4_choose(bin, pr, a, blk - 24, blk - 1, 24, mpred, MUL_LAMBDA(3, m.lambda_q4), L.i4s, lut01, lut23);
+        STAMP(L, 31);
         const int mode = res & 15, sad = res >> 4;
         L.i4_left[r] = B.i4_top[c] = (int8_t)mode;
         L.i4_mode[n] = (int8_t)(mode == mpred ? -1 : mode > mpred ? mode - 1 : mode);
@@ -748,6 +748,7 @@ template <class BOUND> DEV int intra4_choose(RowLds &L, MbBuf &B, const MbCtx &m
             }
             wave_sync();
         }
+        STAMP(L, 18);
         nz_mask = (nz_mask << 1) | coded;
     }
     nz_mask_out = nz_mask & 0xffff;

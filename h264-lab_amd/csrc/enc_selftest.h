@@ -144,7 +144,8 @@ DEV void stage_selftest(StageLds &S, RowLds &L, int stage, const GLOBAL_AS uint8
             if (l < 16) lds32_store(S.o + 4*l, 0u);
         }
         wave_sync();
-        const int res = wave_i4_choose(S.a, S.o, a[0], S.nb + 4, S.nb + 24 + 3, 24, a[1], a[2], S.i4s);
+        const V64 lut01 = i4_lut_lanes(S.i4s, 0), lut23 = i4_lut_lanes(S.i4s, 1);
+        const int res = wave_i4_choose(S.a, S.o, a[0], S.nb + 4, S.nb + 24 + 3, 24, a[1], a[2], S.i4s, lut01, lut23);
         wave_sync();
         WAVE_FOR(l) { if (l < 16) gstore32((gu8 *)out + 8 + 4*l, lds32(S.o + 4*l)); }
         if (wave_lane() == 0) { oi[0] = res & 15; oi[1] = res >> 4; }

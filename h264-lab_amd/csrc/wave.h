@@ -167,6 +167,7 @@ template <class F> DEV V64 v64_map(const V64 &a, F f) { V64 r; WAVE_FOR(l) r.v[l
 template <class F> DEV void v64_each(const V64 &a, F f) { WAVE_FOR(l) f(l, a.v[l]); }
 DEV V64 v64_quad_sum(const V64 &a) { V64 r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l & ~3] + a.v[(l & ~3) + 1] + a.v[(l & ~3) + 2] + a.v[(l & ~3) + 3]; return r; }
 DEV int v64_read(const V64 &a, int lane) { return a.v[lane]; }
+DEV int v64_own(const V64 &a, int lane) { return a.v[lane]; }          /* inside a lane section: this lane's own value */
 DEV uint64_t v64_nonzero_ballot(const V64 &a) { uint64_t m = 0; for (int l = 0; l < 64; l++) if (a.v[l]) m |= 1ull << l; return m; }
 #define PROF_ROW_BEGIN(L) do { } while (0)
 #define PROF_ROW_SYNC(L) do { } while (0)
@@ -369,6 +370,7 @@ DEV V64 v64_quad_sum(const V64 &a)
     return r;
 }
 DEV int v64_read(const V64 &a, int lane) { return __builtin_amdgcn_readlane(a.v, lane); }
+DEV int v64_own(const V64 &a, int) { return a.v; }                     /* inside a lane section: this lane's own value */
 DEV uint64_t v64_nonzero_ballot(const V64 &a) { return __ballot(a.v != 0); }
 #endif
 
