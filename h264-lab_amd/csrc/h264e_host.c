@@ -1436,44 +1436,53 @@ static void *multi_thread(void *p)
  */
 int H264E_clip_encode_multi(H264E_clip_t **clips, int nclips, uint8_t **out, const size_t *cap, size_t *out_bytes, int **frame_bytes, H264E_clip_stats_t *stats)
 {
-    h264e_hip_group_t *g = NULL;
     multi_arg_t *a;
     pthread_t *th;
-    int i, rc = 0, started = 0, saved_base[8] = { 0 };
+    int i, rc = 0, done = 0, saved_base[8] = { 0 };
     g_host_err[0] = 0;
     if (!clips || nclips <= 0 || nclips > 8 || !out || !cap || !out_bytes) { snprintf(g_host_err, sizeof(g_host_err), "clip_encode_multi: bad argument"); return -1; }
+    for (i = 0; i < nclips; i++) if (!clips[i]) { snprintf(g_host_err, sizeof(g_host_err), "clip_encode_multi: clip %d is NULL", i); return -1; }
     if (nclips == 1) return H264E_clip_encode(clips[0], out[0], cap[0], &out_bytes[0], frame_bytes ? frame_bytes[0] : NULL, 0, stats);
     a = (multi_arg_t *)calloc((size_t)nclips, sizeof(*a));
     th = (pthread_t *)calloc((size_t)nclips, sizeof(*th));
-    if (!a || !th || h264e_hip_group_create(&g, clips[0] ? clips[0]->par.device : 0)) { free(a); free(th); if (!g_host_err[0]) snprintf(g_host_err, sizeof(g_host_err), "clip_encode_multi: %s", h264e_hip_last_error()); return -1; }
-    for (i = 0; i < nclips && !rc; i++)
-        if (!clips[i] || h264e_hip_group_join(g, clips[i]->pool)) { snprintf(g_host_err, sizeof(g_host_err), "clip_encode_multi: clip %d cannot join (%s)", i, h264e_hip_last_error()); rc = -1; }
-    for (i = 0; i < nclips && !rc; i++)
+    if (!a || !th) { free(a); free(th); snprintf(g_host_err, sizeof(g_host_err), "out of host memory"); return -1; }
+    /* one launch group per batch: a group holds as many streams of this picture size as one grid can carry safely (h264e_pool.h
+     * h264e_hip_group_join: 5 at 1080p, 2 at 4K, 1 at 8K); the clips that do not fit go in the next batch */
+    while (done < nclips && !rc)
     {
-        /* The members' launches run in lock step, so a member that was stopped by a mis-speculation idles until the round's longest
-         * launch is over: streams with frequent events (single slice, constant QP) get shorter launches inside a group -- a third of
-         * the pipeline depth -- which costs streams WITHOUT staggered events a few percent and gives staggered ones 13 %
-         * (measured, 4 different 1080p clips: 12.8 -> 14.6 M MB/s aggregate; 4 identical ones 21.4 -> 20.7 M) */
-        saved_base[i] = clips[i]->launch_base;
-        if (clips[i]->par.slices <= 1 && clips[i]->gop_len > 1 && clips[i]->par.kbps == 0)
+        h264e_hip_group_t *g = NULL;
+        int first = done, n = 0, started = 0;
+        if (h264e_hip_group_create(&g, clips[first]->par.device)) { snprintf(g_host_err, sizeof(g_host_err), "clip_encode_multi: %s", h264e_hip_last_error()); rc = -1; break; }
+        while (first + n < nclips && !h264e_hip_group_join(g, clips[first + n]->pool)) n++;
+        if (!n) { snprintf(g_host_err, sizeof(g_host_err), "clip_encode_multi: clip %d cannot join a launch group (%s)", first, h264e_hip_last_error()); h264e_hip_group_destroy(g); rc = -1; break; }
+        for (i = first; i < first + n; i++)
         {
-            clips[i]->launch_base = imax(8, clips[i]->launch_base/3);
-            clips[i]->launch_frames = imin(clips[i]->launch_frames, clips[i]->launch_base);
+            /* The members' launches run in lock step, so a member that was stopped by a mis-speculation idles until the round's longest
+             * launch is over: streams with frequent events (single slice, constant QP) get shorter launches inside a group -- a third of
+             * the pipeline depth -- which costs streams WITHOUT staggered events a few percent and gives staggered ones 13 %
+             * (measured, 4 different 1080p clips: 12.8 -> 14.6 M MB/s aggregate; 4 identical ones 21.4 -> 20.7 M) */
+            saved_base[i] = clips[i]->launch_base;
+            if (n > 1 && clips[i]->par.slices <= 1 && clips[i]->gop_len > 1 && clips[i]->par.kbps == 0)
+            {
+                clips[i]->launch_base = imax(8, clips[i]->launch_base/3);
+                clips[i]->launch_frames = imin(clips[i]->launch_frames, clips[i]->launch_base);
+            }
+            a[i].clip = clips[i]; a[i].group = g; a[i].out = out[i]; a[i].cap = cap[i]; a[i].out_bytes = &out_bytes[i];
+            a[i].frame_bytes = frame_bytes ? frame_bytes[i] : NULL; a[i].st = stats ? &stats[i] : NULL;
+            if (pthread_create(&th[i], NULL, multi_thread, &a[i])) { snprintf(g_host_err, sizeof(g_host_err), "clip_encode_multi: cannot start a thread"); rc = -1; break; }
+            started++;
         }
-        a[i].clip = clips[i]; a[i].group = g; a[i].out = out[i]; a[i].cap = cap[i]; a[i].out_bytes = &out_bytes[i];
-        a[i].frame_bytes = frame_bytes ? frame_bytes[i] : NULL; a[i].st = stats ? &stats[i] : NULL;
-        if (pthread_create(&th[i], NULL, multi_thread, &a[i])) { snprintf(g_host_err, sizeof(g_host_err), "clip_encode_multi: cannot start a thread"); rc = -1; break; }
-        started++;
+        /* a clip whose thread never started must not be waited for by the others */
+        for (i = first + started; i < first + n; i++) h264e_hip_group_leave(g, clips[i]->pool);
+        for (i = first; i < first + started; i++)
+        {
+            pthread_join(th[i], NULL);
+            if (a[i].rc && !rc) { rc = a[i].rc; snprintf(g_host_err, sizeof(g_host_err), "clip %d: %s", i, a[i].err); }
+        }
+        for (i = first; i < first + n; i++) if (saved_base[i] > 0) clips[i]->launch_base = saved_base[i];
+        h264e_hip_group_destroy(g);
+        done = first + n;
     }
-    /* a clip whose thread never started must not be waited for by the others */
-    for (i = started; i < nclips; i++) if (clips[i]) h264e_hip_group_leave(g, clips[i]->pool);
-    for (i = 0; i < started; i++)
-    {
-        pthread_join(th[i], NULL);
-        if (a[i].rc && !rc) { rc = a[i].rc; snprintf(g_host_err, sizeof(g_host_err), "clip %d: %s", i, a[i].err); }
-    }
-    for (i = 0; i < nclips; i++) if (clips[i] && saved_base[i] > 0) clips[i]->launch_base = saved_base[i];
-    h264e_hip_group_destroy(g);
     free(a); free(th);
     return rc;
 }

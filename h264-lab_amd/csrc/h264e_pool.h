@@ -694,7 +694,11 @@ extern "C" int h264e_hip_group_join(h264e_hip_group_t *g, h264e_hip_pool_t *p)
 {
     if (!g || !p || p->group) FAIL("group_join: bad argument");
     pthread_mutex_lock(&g->mu);
-    int bad = g->nmembers >= H264E_GROUP_MAX || p->device != g->device || g->arrived;
+    /* how many streams one grid can hold: a far reference read waits for a workgroup up to (12 - lag) dispatch keys AHEAD of its own
+     * (enc_kernels.h rv_wait_rect), i.e. about (12 - lag)*(nmby + 1)/2 workgroups per member stream, and all of those must be resident
+     * together with the waiting one -- out of the ~1536 two-wave workgroups the chip holds at 3 waves per SIMD, with a margin */
+    const int window = (12 - H264E_NARROW_FRAME_LAG)*(p->G.nmby + 1)/2, room = 1400/(window > 0 ? window : 1);
+    int bad = g->nmembers >= H264E_GROUP_MAX || (g->nmembers >= 1 && g->nmembers >= room) || p->device != g->device || g->arrived;
     if (!bad && g->nmembers)
     {
         const h264e_geom_t &A = g->member[0]->G, &B = p->G;
@@ -702,7 +706,7 @@ extern "C" int h264e_hip_group_join(h264e_hip_group_t *g, h264e_hip_pool_t *p)
     }
     if (!bad) { g->member[g->nmembers++] = p; p->group = g; }
     pthread_mutex_unlock(&g->mu);
-    if (bad) FAIL("group_join: the group is full, busy, on another device or holds another picture size");
+    if (bad) FAIL("group_join: the group is full (at most %d streams of this picture size share a launch), busy, on another device or holds another picture size", room < H264E_GROUP_MAX ? room : H264E_GROUP_MAX);
     return 0;
 }
 

@@ -103,3 +103,19 @@ def test_launch_group_of_unequal_streams(P):
         e.close()
     for (out, sizes, st), (wb, ws) in zip(res, want):
         assert out == wb and sizes == ws
+
+
+def test_launch_groups_are_batched_by_what_one_grid_can_hold(P):
+    """three 4K streams: one grid carries two of that size safely (the far-read window, h264e_hip_group_join), so H264E_clip_encode_multi
+    runs a group of two and then the third by itself; all three streams are the reference's"""
+    g = GOLDEN_BIG["4k_30"]
+    encs = []
+    for k in range(3):
+        ce = P.ClipEncoder(g["w"], g["h"], g["frames"], gop=30, qp=26, max_chains=32)
+        ce.generate_synth()
+        encs.append(ce)
+    res = P.ClipEncoder.encode_multi(encs)
+    for ce in encs:
+        ce.close()
+    for out, sizes, st in res:
+        assert sizes == g["frame_bytes"] and hashlib.md5(out).hexdigest() == g["md5"]
