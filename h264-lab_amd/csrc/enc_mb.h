@@ -431,7 +431,7 @@ DEV int diamond_g(RowLds &L, const MbBuf &B, const MbCtx &m, int px, int py, mv3
  * are independent of each other: every one starts from the macroblock's predictor context (H:3646-3671).  Leaves the type's cost in
  * L.gcost[t], its vectors in L.part_mv[t] / L.part_mvd[t] and its prediction in L.gtest[t].
  */
-DEV void search_type(RowLds &L, const MbBuf &B, const MbCtx &m, int t, mv32 mv_best, int sad_best0, const rect_t &lim)
+DEV void search_type(RowLds &L, const MbBuf &B, const MbCtx &m, int t, mv32 mv_best, int sad_best0, const rect_t &lim, int skip_cost)
 {
     GCtx &X = L.gctx[t];
     int imv = 0, part_sad = MUL_LAMBDA(t == 0 ? 1 : t == 3 ? 12 : 4, m.lambda_q4);
@@ -460,6 +460,10 @@ DEV void search_type(RowLds &L, const MbBuf &B, const MbCtx &m, int t, mv32 mv_b
         mvp_put_arr(X.mv_left, X.mv_tl, X.mv_top, px >> 2, py >> 2, w >> 2, h >> 2, mv);
         wave_sync();
         STAMP(L, 27);
+        /* two waves per row: the 16x16 cost is final after this group's first step -- a tighter bound of the macroblock's inter cost than
+         * the one inter_choose announced (the decision is the minimum over the types, or the skip vector's cost when that minimum lies
+         * above its SAD), for the intra 4x4 cut-off of the reconstruction wave while the other types are still being searched */
+        if (t == 0) L.early_bound = imax(part_sad, skip_cost);
         px = (px + w) & 15;
         if (!px)
         {
@@ -645,7 +649,7 @@ template <class SIG> DEV void inter_choose(RowLds &L, MbBuf &B, MbCtx &m, SIG si
     wave_sync();
     GRP_EACH(t)
     {
-        if ((types >> t) & 1) search_type(L, B, m, t, mv_best, sad_best, lim);
+        if ((types >> t) & 1) search_type(L, B, m, t, mv_best, sad_best, lim, sad_skip != 0x7FFFFFFF ? sad_skip + mv_cost(m, mv_skip, mv_pred16) : 0);
     }
     wave_sync();
     STAMP(L, 5);

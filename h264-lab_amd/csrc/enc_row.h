@@ -83,8 +83,24 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
 
 /* neighbour record of the macroblock above -> LDS (h264-lab.h:742-745 contexts, :590-606 deblock state): 16 coherent dword
  * loads of the record (+2 of the record to its right), staged in LDS, then unpacked */
-DEV void load_top(RowLds &L, MbBuf &B, const h264e_geom_t &G, const GLOBAL_AS h264e_mbbottom_t *above, const GLOBAL_AS h264e_mbpend_t *pend_above, int x, int have_top)
+/* part: LOAD_TOP_ALL, or -- two waves per row -- LOAD_TOP_MV for the search wave (the vectors of the macroblock above and of the one to its
+ * right: all the search needs, and available as soon as the row above has DECIDED them, h264e_kernels.hip) and LOAD_TOP_REST for the
+ * reconstruction wave (samples, contexts, pending lines: what the row above writes at the end of its macroblock) */
+#define LOAD_TOP_ALL 0
+#define LOAD_TOP_MV 1
+#define LOAD_TOP_REST 2
+template <int PART> DEV void load_top(RowLds &L, MbBuf &B, const h264e_geom_t &G, const GLOBAL_AS h264e_mbbottom_t *above, const GLOBAL_AS h264e_mbpend_t *pend_above, int x, int have_top)
 {
+    if (PART == LOAD_TOP_MV)
+    {
+        WAVE_FOR(l)
+        {
+            if (l < 4) B.mv_top[l] = have_top ? (mv32)cload32((const gu8 *)(above + x) + 32 + 4*l) : 0;
+            else if (l == 4) B.mv_top[4] = (have_top && x + 1 < G.nmbx) ? (mv32)cload32((const gu8 *)(above + x + 1) + 32) : 0;
+        }
+        wave_sync();
+        return;
+    }
     if (have_top)
     {
         WAVE_FOR(l)
@@ -98,19 +114,19 @@ DEV void load_top(RowLds &L, MbBuf &B, const h264e_geom_t &G, const GLOBAL_AS h2
         WAVE_FOR(l)
         {
             if (l < 8) lds32_store(B.pix_top + 4*l, lds32(L.trec + 4*l));
-            else if (l < 12) B.mv_top[l - 8] = (mv32)lds32(L.trec + 32 + 4*(l - 8));
+            else if (l < 12) { if (PART == LOAD_TOP_ALL) B.mv_top[l - 8] = (mv32)lds32(L.trec + 32 + 4*(l - 8)); }
             else if (l < 20) B.nnz_top[l - 12] = L.trec[48 + l - 12];
             else if (l < 24) B.i4_top[l - 20] = (int8_t)L.trec[56 + l - 20];
             else if (l == 24) { B.df_nz_top = L.trec[60]; B.top_type = (int8_t)L.trec[61]; B.top_qp = L.trec[62]; }
             else if (l == 25) lds32_store(B.pix_top + 32, lds32(L.trec + 64));
-            else if (l == 26) B.mv_top[4] = (mv32)lds32(L.trec + 68);
+            else if (l == 26) { if (PART == LOAD_TOP_ALL) B.mv_top[4] = (mv32)lds32(L.trec + 68); }
         }
     } else
     {
         WAVE_FOR(l)
         {
             if (l < 36) B.pix_top[l] = 0;
-            if (l < 5) B.mv_top[l] = 0;
+            if (l < 5 && PART == LOAD_TOP_ALL) B.mv_top[l] = 0;
             if (l < 8) B.nnz_top[l] = NNZ_NA;
             if (l < 4) B.i4_top[l] = -1;
             if (l == 0) { B.df_nz_top = 0; B.top_type = 0; B.top_qp = 0; }
@@ -223,6 +239,7 @@ struct InterIsThere
 {
     DEVM bool ready() const { return true; }
     DEVM bool wait_noskip_or_ready() const { return true; }
+    DEVM bool wait_bound_or_ready() const { return true; }
     DEVM bool wait_ready() const { return true; }
     DEVM int early_bound() const { return 0x7fffffff; }
 };
@@ -246,6 +263,9 @@ template <class P> DEV bool mb_intra_decide(RowLds &L, MbBuf &B, MbCtx &m, const
         STAMP(L, 8);
         int cost4 = I4_LOST, bnd = imin(m.cost, cost16);
         unsigned nz4 = 0;
+        /* the 4x4 candidates cost three times the 16x16 one and lose against most inter decisions after a few blocks -- once there is a
+         * bound to lose against: wait for the search wave's first one (it follows the early-skip test by one candidate scan) */
+        if (!have && !pol.wait_bound_or_ready()) return false;
         if (T.speed < 2 || T.slice_type != 0)
             cost4 = intra4_choose(L, B, m, [&]() -> int {
                 if (!have)
@@ -267,12 +287,14 @@ template <class P> DEV bool mb_intra_decide(RowLds &L, MbBuf &B, MbCtx &m, const
 }
 
 /* reconstruction side, second half */
-template <int GEOM> DEV void mb_recon_write(RowLds &L, MbBuf &B, MbCtx &m, const h264e_geom_t &G, const ChainG &C, const RowTask &T, int row, int x, int row0, int row1)
+struct NoHook { DEVM void operator()() const {} };
+template <int GEOM, class HOOK> DEV void mb_recon_write(RowLds &L, MbBuf &B, MbCtx &m, const h264e_geom_t &G, const ChainG &C, const RowTask &T, int row, int x, int row0, int row1, HOOK after_prediction)
 {
     const bool have_top = row > row0;
     GLOBAL_AS h264e_mbbottom_t *rowrec = C.bottom + (size_t)row*G.nmbx;
     if (GEOM == GEOM_INTRA || m.type >= 5) wave_pred_chroma(L.pred_c, L.pix_left + 16, B.pix_top + 16, m.avail, m.i16_mode);
     else predict_chroma_inter(B, m, L.pred_c);
+    after_prediction();             /* two waves per row: the `decided` counter (h264e_kernels.hip) */
 
     STAMP(L, 10);
     BitW bw = L.bw;
@@ -447,11 +469,11 @@ template <int GEOM> DEV void row_step(RowLds &L, const h264e_geom_t &G, const Ch
 {
     MbBuf &B = L.mb[x & 1];
     MbCtx m;
-    load_top(L, B, G, C.bottom + (size_t)(row - 1)*G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, row > row0);
+    load_top<LOAD_TOP_ALL>(L, B, G, C.bottom + (size_t)(row - 1)*G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, row > row0);
     mb_search<GEOM>(L, B, G, T, row, x, row0, NoSignals());
     mb_ctx_init<GEOM>(m, L, G, T, row, x, row0, 1);
     mb_intra_decide(L, B, m, T, InterIsThere());
-    mb_recon_write<GEOM>(L, B, m, G, C, T, row, x, row0, row1);
+    mb_recon_write<GEOM>(L, B, m, G, C, T, row, x, row0, row1, NoHook{});
 }
 
 DEV void row_end(RowLds &L, const h264e_geom_t &G, const ChainG &C, int row)

@@ -75,16 +75,18 @@ struct InterFromSearchWave
     DEVM bool ready() const { return uni(flag_get(&L->f_inter)) >= need; }
     DEVM bool wait_ready() const { return lds_wait(&L->f_inter, need, &L->f_stop) == 0; }
     DEVM int early_bound() const { return uni(flag_get(&L->f_bound)) >= need ? uni(L->early_bound) : 0x7fffffff; }
-    DEVM bool wait_noskip_or_ready() const
+    DEVM bool wait_either(const int *f) const
     {
         for (unsigned spins = 0;; spins++)
         {
-            if (uni(flag_get(&L->f_inter)) >= need || uni(flag_get(&L->f_noskip)) >= need) return true;
+            if (uni(flag_get(&L->f_inter)) >= need || uni(flag_get(f)) >= need) return true;
             if (uni(flag_get(&L->f_stop))) return false;
             if (spins > LDS_SPIN_LIMIT) { flag_set(&L->f_stop, -1); return false; }
             __builtin_amdgcn_s_sleep(1);
         }
     }
+    DEVM bool wait_noskip_or_ready() const { return wait_either(&L->f_noskip); }
+    DEVM bool wait_bound_or_ready() const { return wait_either(&L->f_bound); }
 };
 
 /*
@@ -306,13 +308,16 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
             if (!st) row_prefetch<GEOM>(L, G, RT, row, x);
             STAMP(L, 0);
             /* ... so that their latency overlaps with the wait for the row above */
+            /* two waves: the search needs only the VECTORS of the row above, which that row's reconstruction wave hands over as soon as
+             * they are decided (its `decided` counter, behind the progress counters) -- a transform / CAVLC / deblocking earlier than
+             * the rest of the record, which this row's reconstruction wave waits for */
             if (!st && seen < need)
             {
-                st = poll_progress(C.progress + (row - 1), need, seen, G.spin_limit);
+                st = poll_progress(C.progress + (WAVES == 2 ? G.nmby : 0) + (row - 1), need, seen, G.spin_limit);
                 if (!st) consumer_acquire();
             }
             STAMP(L, 13);
-            if (!st) load_top(L, L.mb[x & 1], G, C.bottom + (size_t)(row - 1)*G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, row > row0);
+            if (!st) load_top<WAVES == 2 ? LOAD_TOP_MV : LOAD_TOP_ALL>(L, L.mb[x & 1], G, C.bottom + (size_t)(row - 1)*G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, row > row0);
             /* two waves: the search of x starts from the predictor context the decision of x - 1 leaves behind */
             STAMP(L, 0);
             if (WAVES == 2 && !st && x >= 1) st = lds_wait(&L.f_decided, x, &L.f_stop);
@@ -364,25 +369,49 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
     {
         /* ---- the reconstruction wave of the two-wave pipeline: intra candidates + decision of x, then transform / CAVLC / deblocking /
          * stores of x while the search wave is already on x + 1 */
+        GLOBAL_AS int *my_decided = my_progress + G.nmby;
+        GLOBAL_AS h264e_mbbottom_t *rowrec = C.bottom + (size_t)row*G.nmbx;
+        int seen = 0;
         for (int x = 0; x < G.nmbx; x++)
         {
             MbBuf &B = L.mb[x & 1];
             MbCtx m;
             mb_ctx_init<GEOM>(m, L, G, RT, row, x, row0, 1);
             int ff = 0;
-            if (!mb_intra_decide(L, B, m, RT, InterFromSearchWave{ &L, x + 1 })) ff = uni(flag_get(&L.f_stop));
-            else
+            /* samples, contexts and pending lines of the row above: complete when its reconstruction wave has published x + 1 */
+            const int need = row > row0 ? imin(x + 2, G.nmbx) : 0;
+            if (seen < need)
             {
-                flag_set(&L.f_decided, x + 1);
-                mb_recon_write<GEOM>(L, B, m, G, C, RT, row, x, row0, row1);
-                ff = uni(L.far_fail[1]);
-                if (ff) { ff = ff < -2 ? -2 : ff; flag_set(&L.f_stop, ff); }
+                ff = poll_progress(C.progress + (row - 1), need, seen, G.spin_limit);
+                if (!ff) consumer_acquire();
+                else flag_set(&L.f_stop, ff);
+            }
+            STAMP(L, 17);
+            if (!ff)
+            {
+                load_top<LOAD_TOP_REST>(L, B, G, C.bottom + (size_t)(row - 1)*G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, row > row0);
+                if (!mb_intra_decide(L, B, m, RT, InterFromSearchWave{ &L, x + 1 })) ff = uni(flag_get(&L.f_stop));
+                else
+                {
+                    flag_set(&L.f_decided, x + 1);
+                    /* the vectors of this macroblock's bottom row, for the search of the row below: on their way while the chroma
+                     * prediction runs, published before the transform starts */
+                    WAVE_FOR(l) { if (l < 4) cstore32((gu8 *)(rowrec + x) + 32 + 4*l, (uint32_t)B.mv_top[l]); }
+                    mb_recon_write<GEOM>(L, B, m, G, C, RT, row, x, row0, row1, [&]() {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                        if (LANE == 0) __hip_atomic_store(my_decided, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    });
+                    ff = uni(L.far_fail[1]);
+                    if (ff) { ff = ff < -2 ? -2 : ff; flag_set(&L.f_stop, ff); }
+                }
             }
             if (ff)
             {
                 if (LANE == 0)
                 {
                     if (ff == -1) *errflag = 1;
+                    __hip_atomic_store(my_decided, ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(my_progress, ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 return;

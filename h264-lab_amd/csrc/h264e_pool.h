@@ -349,7 +349,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         p->clip = (uint8_t *)carve(p->frame_bytes*(size_t)frames_resident, 4096);
         p->chains_dev = (h264e_chain_dev_t *)carve(sizeof(h264e_chain_dev_t)*(size_t)nchains, 256);
         p->tasks_dev = (h264e_frame_task_t *)carve(sizeof(h264e_frame_task_t)*(size_t)nchains*TASK_RING, 256);
-        p->progress_all = (int *)carve(sizeof(int)*(size_t)nchains*G.nmby, 256);
+        p->progress_all = (int *)carve(sizeof(int)*2*(size_t)nchains*G.nmby, 256);     /* per slot: nmby row counters, then nmby `decided` counters */
         p->errflag = (int *)carve(sizeof(int), 256);
         p->stepflags = (int *)carve(sizeof(int)*2*(size_t)nchains, 256);
         p->abort_dev = (int *)carve(64, 256);
@@ -370,7 +370,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
             }
             C.bottom = (h264e_mbbottom_t *)carve(sizeof(h264e_mbbottom_t)*(size_t)G.nmb, 256);
             C.pend = (h264e_mbpend_t *)carve(sizeof(h264e_mbpend_t)*(size_t)G.nmb, 256);
-            C.progress = p->progress_all + (size_t)c*G.nmby;
+            C.progress = p->progress_all + (size_t)c*2*G.nmby;
             C.rowbits = (uint32_t *)carve(sizeof(uint32_t)*(size_t)G.nmby*G.row_words, 256);
             C.rowmeta = (h264e_rowmeta_t *)carve(sizeof(h264e_rowmeta_t)*(size_t)G.nmby, 256);
             C.mbrec = (h264e_mbrec_t *)carve(sizeof(h264e_mbrec_t)*(size_t)G.nmb*slots, 256);
@@ -879,7 +879,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     /* pageable source: the runtime stages the copy before returning, so `host` can be freed right away */
     hipError_t e = hipMemcpyAsync(slot, host, sizeof(h264e_frame_task_t)*(size_t)p->nchains, hipMemcpyHostToDevice, p->stream);
     if (e != hipSuccess) { free(host); FAIL("task upload: %s", hipGetErrorString(e)); }
-    e = hipMemsetAsync(p->progress_all, 0, sizeof(int)*(size_t)p->nchains*G.nmby, p->stream);
+    e = hipMemsetAsync(p->progress_all, 0, sizeof(int)*2*(size_t)p->nchains*G.nmby, p->stream);
     /* rows kept from the previous encode of a frame count as complete */
     for (int c = 0; c < p->nchains && e == hipSuccess; c++)
         if (host[c].active && host[c].first_row > 0)
@@ -888,6 +888,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
             if (!done) { e = hipErrorOutOfMemory; break; }
             for (int r = 0; r < host[c].first_row; r++) done[r] = G.nmbx + 1;
             e = hipMemcpyAsync(p->chains_host[host[c].chain].progress, done, sizeof(int)*(size_t)host[c].first_row, hipMemcpyHostToDevice, p->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(p->chains_host[host[c].chain].progress + G.nmby, done, sizeof(int)*(size_t)host[c].first_row, hipMemcpyHostToDevice, p->stream);
             free(done);         /* pageable source: staged before the call returns */
         }
     if (e != hipSuccess) { free(host); FAIL("progress reset: %s", hipGetErrorString(e)); }

@@ -12,9 +12,9 @@ from __graft_entry__ import _pkg  # noqa: E402
 
 NAMES = {0: "S load input + window + records above", 1: "S setup", 2: "S inter: predictors", 3: "S inter: skip test", 4: "S inter: candidates", 5: "S inter: partition search: entry/exit", 24: "S   search: set-up per partition (predictor, range, start SAD)", 25: "S   search: full-pel scan", 26: "S   search: sub-pel", 27: "S   search: bookkeeping",
          7: "S inter: rest", 13: "S WAIT row above / reference frame (poll+acquire)", 23: "S wait: hand-off buffer free (R wave 2 MBs behind)", 6: "S wait: decision of x-1 (R wave)",
-         15: "R wait: search wave's skip test", 8: "R intra 16x16", 9: "R intra 4x4: entry/exit", 19: "R   i4: per-block control (availability, contexts, cut-off)", 31: "R   i4: mode choice (9 predictions + SADs)", 18: "R   i4: transform / quantiser / reconstruction", 16: "R wait: inter decision", 10: "R merge + contexts + chroma prediction",
+         17: "R WAIT row above (rest of its record: poll+acquire)", 15: "R wait: search wave's skip test", 8: "R intra 16x16", 9: "R intra 4x4: entry/exit", 19: "R   i4: per-block control (availability, contexts, cut-off)", 31: "R   i4: mode choice (9 predictions + SADs)", 18: "R   i4: transform / quantiser / reconstruction", 16: "R wait: inter decision", 10: "R merge + contexts + chroma prediction",
          11: "R mb_write (xform/quant/CAVLC/recon)", 12: "R ctx save + deblock + stores", 14: "publish / signal"}
-ORDER = [13, 23, 0, 6, 1, 2, 3, 4, 5, 24, 25, 26, 27, 7, 15, 8, 9, 19, 31, 18, 16, 10, 11, 12, 14]
+ORDER = [13, 23, 0, 6, 1, 2, 3, 4, 5, 24, 25, 26, 27, 7, 17, 15, 8, 9, 19, 31, 18, 16, 10, 11, 12, 14]
 SEARCH_SIDE = {13, 23, 0, 6, 1, 2, 3, 4, 5, 24, 25, 26, 27, 7}
 
 
