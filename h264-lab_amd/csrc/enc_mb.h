@@ -640,6 +640,9 @@ template <class SIG> DEV void inter_choose(RowLds &L, MbBuf &B, MbCtx &m, SIG si
      * four lane groups side by side (search_type).  The reference takes a type when its cost is strictly below the best so far, in the
      * order 16x16, 16x8, 8x16, 8x8 (H:5500): the minimum, the earliest type on ties. */
     const int types = 1 | (prefer[1] ? 2 : 0) | (prefer[2] ? 4 : 0) | (prefer[3] ? 8 : 0);
+#ifdef H264E_TYPES_PROBE
+    PCOUNT(L, 20 + (types == 1 ? 0 : (types & 8) ? 2 : 1));
+#endif
     WAVE_FOR(l)
     {
         const int i = l & 15;

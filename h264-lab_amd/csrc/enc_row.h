@@ -461,7 +461,9 @@ template <int GEOM, class HOOK> DEV void mb_recon_write(RowLds &L, MbBuf &B, MbC
     L.left_qp = T.qp;
     wave_sync();
     STAMP(L, 12);
+#ifndef H264E_TYPES_PROBE
     PCOUNT(L, 20 + (m.type < 0 ? 0 : m.type < 5 ? 1 : 2));
+#endif
 }
 
 /* the three phases one after the other: one wavefront per row, and the emulation */
