@@ -391,12 +391,15 @@ template <int GEOM, class HOOK> DEV void mb_recon_write(RowLds &L, MbBuf &B, MbC
     if (!T.no_deblock)
     {
         /* the neighbour samples the filter changed: 3 luma / 1 chroma columns of the left macroblock (picture, or its pending
-         * record for the bottom lines), and the 4 luma / 2 chroma lines above, which are final now */
+         * record for the bottom lines) -- unless the left edge was not filtered at all (strength 0 on all of it: two skipped
+         * macroblocks side by side), then what the left macroblock stored itself stands -- and the 4 luma / 2 chroma lines above,
+         * which are final now */
+        const bool left_filtered = x > 0 && uni(lds32(L.bs)) != 0;
         WAVE_FOR(l)
         {
             if (l < 16)
             {
-                if (x > 0)
+                if (left_filtered)
                 {
                     uint32_t v = lds32(L.ytile + (4 + l)*YT_STRIDE);
                     if (l < 12 || direct) cstore32(dy + (size_t)l*W - 4, v);
@@ -415,7 +418,7 @@ template <int GEOM, class HOOK> DEV void mb_recon_write(RowLds &L, MbBuf &B, MbC
             } else if (l < 48)
             {
                 int pl = (l - 32) >> 3, i = (l - 32) & 7;
-                if (x > 0)
+                if (left_filtered)
                 {
                     /* columns 4..7 of the left macroblock as one dword: 4..6 as it left them, 7 as this filter left it */
                     const uint32_t v = (uint32_t)L.strip_c[pl][4*i] | ((uint32_t)L.strip_c[pl][4*i + 1] << 8) | ((uint32_t)L.strip_c[pl][4*i + 2] << 16) |
