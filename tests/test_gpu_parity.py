@@ -172,6 +172,27 @@ def test_1080p_long_clip_is_invariant(P):
     assert outs[0] == outs[1] == outs[2] == outs[3]
 
 
+@pytest.mark.parametrize("waves", [1, 2, 4])
+@pytest.mark.parametrize("name,w,h,n,gop,slices", [("synth", 352, 288, 9, 4, 0), ("pan", 640, 368, 6, 30, 3), ("scene", 200, 120, 7, 7, 0)])
+def test_every_kernel_variant_matches_oracle(P, monkeypatch, waves, name, w, h, n, gop, slices):
+    """the macroblock kernel exists in variants chosen per launch (h264e_kernels.hip bk_launch_mb): one wave per row, two waves per row
+    at 3 and at 4 waves per SIMD (H264E_WAVES forces one; all-intra launches always take the intra-only kernel).  The decisions must
+    not depend on the variant: every one, both window geometries, with and without row-band slices, against the oracle"""
+    monkeypatch.setenv("H264E_WAVES", str(waves))
+    c = clips.make(name, w, h, n)
+    want, sizes = oracle_lib.encode_clip(c, w, h, gop=gop, qp=27, slices=slices)
+    ce = P.ClipEncoder(w, h, n, gop=gop, qp=27, slices=slices)
+    ce.upload(c)
+    out, fs, st = ce.encode()
+    ce.close()
+    assert fs == sizes
+    assert out == want
+    e = P.Encoder(w, h, gop=gop, qp=27, slices=slices)
+    got = b"".join(e.encode(c[t]) for t in range(n))
+    e.close()
+    assert got == want
+
+
 @pytest.mark.parametrize("w,h,n", [(3840, 2160, 3), (7680, 4320, 2)])
 def test_4k_8k_match_oracle(P, w, h, n):
     """BASELINE configs[3]/[4] geometry (32 400 / 129 600 macroblocks per frame, 8K is cropped): I + P frames"""
