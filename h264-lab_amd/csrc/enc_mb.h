@@ -339,6 +339,9 @@ DEV int diamond_g(RowLds &L, const MbBuf &B, const MbCtx &m, int px, int py, mv3
 #undef DX
 #undef DY
 
+#ifdef H264E_ABLATE
+    if (H264E_ABLATE == 3) { grp_interp_luma(R, px, py, mv, w, h, dst); return min_sad; }
+#endif
     if (!(m.speed < 9 && in_rect(mv, mv_qlimit(m))))
     {
         grp_interp_luma(R, px, py, mv, w, h, dst);
@@ -639,6 +642,10 @@ template <class SIG> DEV void inter_choose(RowLds &L, MbBuf &B, MbCtx &m, SIG si
     /* H:3646-3671: every partitioning is tried from the same predictor state; H:5283-5524's loop over the partition types runs as
      * four lane groups side by side (search_type).  The reference takes a type when its cost is strictly below the best so far, in the
      * order 16x16, 16x8, 8x16, 8x8 (H:5500): the minimum, the earliest type on ties. */
+#ifdef H264E_ABLATE      /* what-if timing builds (tools/gpu_ablate.sh): NOT bit-exact, never the product */
+    if (H264E_ABLATE == 1) prefer[3] = 0;
+    if (H264E_ABLATE == 4) prefer[1] = prefer[2] = prefer[3] = 0;
+#endif
     const int types = 1 | (prefer[1] ? 2 : 0) | (prefer[2] ? 4 : 0) | (prefer[3] ? 8 : 0);
 #ifdef H264E_TYPES_PROBE
     PCOUNT(L, 20 + (types == 1 ? 0 : (types & 8) ? 2 : 1));

@@ -266,6 +266,9 @@ template <class P> DEV bool mb_intra_decide(RowLds &L, MbBuf &B, MbCtx &m, const
         /* the 4x4 candidates cost three times the 16x16 one and lose against most inter decisions after a few blocks -- once there is a
          * bound to lose against: wait for the search wave's first one (it follows the early-skip test by one candidate scan) */
         if (!have && !pol.wait_bound_or_ready()) return false;
+#ifdef H264E_ABLATE
+        if (H264E_ABLATE != 2)
+#endif
         if (T.speed < 2 || T.slice_type != 0)
             cost4 = intra4_choose(L, B, m, [&]() -> int {
                 if (!have)
