@@ -8,8 +8,8 @@ B=$R/tests/emu/build_asan
 S=$R/h264-lab_amd/csrc
 mkdir -p $B
 F="-O1 -g -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer"
-gcc $F -c $S/h264e_host.c -o $B/host.o
-g++ -std=c++17 $F -DH264E_EMU -x c++ -c $S/h264e_kernels.hip -o $B/emu.o
+gcc $F -Wno-format-truncation -c $S/h264e_host.c -o $B/host.o
+(cd $R/tests/emu && g++ -std=c++17 $F -DH264E_EMU -c emu_backend.cpp -o $B/emu.o)
 g++ -shared -fsanitize=address,undefined -o $B/libh264e_emu_asan.so $B/emu.o $B/host.o
 gcc -O1 -g -fsanitize=address,undefined -o $B/encode_app_asan $S/encode_app.c -L$B -lh264e_emu_asan -Wl,-rpath,'$ORIGIN' -lm -lpthread
 cd $R
