@@ -63,13 +63,17 @@ struct RowLds
     BitW bw;
     int skip_run, lead_skips, coded_any;
     /* ---- both sides */
-    int far_reads[2];                               /* reference accesses of this row that left the valid window (search / reconstruction side) */
-    int far_fail[2];                                /* a dynamic wait behind such an access gave up (enc_kernels.h rv_wait_rect): -1 expired, -2 producer aborted */
+    int far_reads[3];                               /* reference accesses of this row that left the valid window (search / reconstruction side / 8x8 search helper) */
+    int far_fail[3];                                /* a dynamic wait behind such an access gave up (enc_kernels.h rv_wait_rect): -1 expired, -2 producer aborted */
     int16_t slice_row[H264E_MAX_SLICES + 2];       /* this frame's slice start rows (copy of the task's) */
-    unsigned long long prof[2][32], prof_last[2], prof_c0, prof_w0;     /* -DH264E_STAMPS diagnostic build only */
+    unsigned long long prof[3][32], prof_last[3], prof_c0, prof_w0;     /* -DH264E_STAMPS diagnostic build only */
     /* hand-off words of the two-wave pipeline (h264e_kernels.hip): monotonic counters "macroblocks done" per stage, and a stop code */
     int f_noskip, f_bound, f_inter, f_decided, f_wdone, f_stop;
     int early_bound;                                /* an upper bound of the inter cost, known right after the candidate evaluation (f_bound) */
+    /* three waves per row (latency-bound launches): the search wave hands the 8x8 partition type to a helper wave */
+    int f_t3req, f_t3done;                          /* macroblocks for which the 8x8 search was requested / is done */
+    int t3_sad_best, t3_lim[4];                     /* the request: start cost, vector limits (the start vector below) */
+    mv32 t3_mv_best;
 
     MbBuf mb[2];
     alignas(4) uint8_t trec[72];                    /* staged record of the macroblock above (+ 8 bytes of the one above-right) */
@@ -532,7 +536,8 @@ DEV int skip_chroma_ok(const MbBuf &B, const MbCtx &m, const uint8_t *pred_c)
 
 /* H:5283-5524 inter_choose_mode */
 /* sig: what the two-wave pipeline wants to hear before the decision is complete (enc_row.h NoSignals / h264e_kernels.hip SearchSignals):
- * noskip() once the early-skip test has failed, bound(u) as soon as an upper bound u of the final inter cost is known */
+ * noskip() once the early-skip test has failed, bound(u) as soon as an upper bound u of the final inter cost is known; helper(): a
+ * third wave searches the 8x8 partition type (t3_request hands it over, t3_wait returns false when the row is being stopped) */
 template <class SIG> DEV void inter_choose(RowLds &L, MbBuf &B, MbCtx &m, SIG sig)
 {
     int prefer[4] = { 1, 0, 0, 0 };      /* constant indices only after unrolling: stays in registers */
@@ -657,11 +662,17 @@ template <class SIG> DEV void inter_choose(RowLds &L, MbBuf &B, MbCtx &m, SIG si
         c[i] = i < 4 ? L.mv_left[i] : i < 8 ? L.mv_tl[i - 4] : i < 13 ? B.mv_top[i - 8] : 0;
     }
     wave_sync();
+    /* three waves per row: the 8x8 type -- a chain of four searches, the long pole of this function -- runs on the helper wave, from the
+     * same start vector and its own copy of the predictor context, while this wave searches the other types */
+    const bool helped = sig.helper() && (types & 8);
+    if (helped) sig.t3_request(mv_best, sad_best, lim);
+    const int types_here = helped ? types & 7 : types;
     GRP_EACH(t)
     {
-        if ((types >> t) & 1) search_type(L, B, m, t, mv_best, sad_best, lim, sad_skip != 0x7FFFFFFF ? sad_skip + mv_cost(m, mv_skip, mv_pred16) : 0);
+        if ((types_here >> t) & 1) search_type(L, B, m, t, mv_best, sad_best, lim, sad_skip != 0x7FFFFFFF ? sad_skip + mv_cost(m, mv_skip, mv_pred16) : 0);
     }
     wave_sync();
+    if (helped && !sig.t3_wait()) { m.type = 0; m.cost = 0xffffff; B.mv[0] = 0; B.mvd[0] = 0; return; }      /* the row is being stopped: nothing of this macroblock is used */
     STAMP(L, 5);
     m.cost = 0xffffff;
     int best_n = 0;

@@ -62,8 +62,8 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
     L.bw.acc = 0; L.bw.nacc = 0; L.bw.pos = 0; L.bw.overflow = 0;
     L.bw.cap = (uint32_t)G.row_words;
     L.bw.buf = C.rowbits + (size_t)row*G.row_words;
-    L.skip_run = 0; L.lead_skips = 0; L.coded_any = 0; L.far_reads[0] = L.far_reads[1] = 0; L.far_fail[0] = L.far_fail[1] = 0;
-    L.f_noskip = L.f_bound = L.f_inter = L.f_decided = L.f_wdone = L.f_stop = 0; L.early_bound = 0;
+    L.skip_run = 0; L.lead_skips = 0; L.coded_any = 0; L.far_reads[0] = L.far_reads[1] = L.far_reads[2] = 0; L.far_fail[0] = L.far_fail[1] = L.far_fail[2] = 0;
+    L.f_noskip = L.f_bound = L.f_inter = L.f_decided = L.f_wdone = L.f_stop = 0; L.early_bound = 0; L.f_t3req = L.f_t3done = 0;
     WAVE_FOR(l) { if (l <= H264E_MAX_SLICES) L.slice_row[l] = l <= T.nslices ? T.slice_row[l] : (int16_t)0x7fff; }
     WAVE_FOR(l)
     {
@@ -222,7 +222,7 @@ template <int GEOM> DEV void mb_ctx_init(MbCtx &m, RowLds &L, const h264e_geom_t
 /* search side.  The input macroblock, the reference window (row_prefetch) and the records of the row above (load_top) are already in
  * LDS.  sig (inter_choose): sig.noskip() is called once the
  * early-skip test has failed (the reconstruction side may start on the intra candidates then). */
-struct NoSignals { DEVM void noskip() const {} DEVM void bound(int) const {} };
+struct NoSignals { DEVM void noskip() const {} DEVM void bound(int) const {} DEVM bool helper() const { return false; } DEVM void t3_request(mv32, int, const rect_t &) const {} DEVM bool t3_wait() const { return true; } };
 template <int GEOM, class SIG> DEV void mb_search(RowLds &L, MbBuf &B, const h264e_geom_t &G, const RowTask &T, int row, int x, int row0, SIG sig)
 {
     MbCtx m;
@@ -496,7 +496,7 @@ DEV void row_end(RowLds &L, const h264e_geom_t &G, const ChainG &C, int row)
     gu8 *M = (gu8 *)(C.rowmeta + row);       /* {nbits, lead_skips, trail_skips, overflow}: read by the finalizer workgroup */
     if (wave_lane() == 0)
     {
-        g_atomic_add(C.far_reads, L.far_reads[0] + L.far_reads[1]);
+        g_atomic_add(C.far_reads, L.far_reads[0] + L.far_reads[1] + L.far_reads[2]);
         cstore32(M, nbits);
         cstore32(M + 4, (uint32_t)(L.coded_any ? L.lead_skips : G.nmbx));
         cstore32(M + 8, (uint32_t)(L.coded_any ? L.skip_run : 0));

@@ -64,8 +64,17 @@ struct SearchSignals
 {
     RowLds *L;
     int need;
+    bool help;          /* three waves per row: a helper wave searches the 8x8 partition type */
     DEVM void noskip() const { flag_set(&L->f_noskip, need); }
     DEVM void bound(int u) const { L->early_bound = u; flag_set(&L->f_bound, need); }
+    DEVM bool helper() const { return help; }
+    DEVM void t3_request(mv32 mv_best, int sad_best, const rect_t &lim) const
+    {
+        L->t3_mv_best = mv_best; L->t3_sad_best = sad_best;
+        L->t3_lim[0] = lim.x0; L->t3_lim[1] = lim.y0; L->t3_lim[2] = lim.x1; L->t3_lim[3] = lim.y1;
+        flag_set(&L->f_t3req, need);            /* release: the request and the predictor context copy (inter_choose) are visible with it */
+    }
+    DEVM bool t3_wait() const { return lds_wait(&L->f_t3done, need, &L->f_stop) == 0; }
 };
 /* the reconstruction wave's view of the inter decision of macroblock need - 1 (enc_row.h mb_intra_decide) */
 struct InterFromSearchWave
@@ -121,7 +130,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
     /* (the intra-only variant allocates the row state without the search-side buffers at its end: enc_mb.h ROWLDS_INTRA_BYTES) */
     __shared__ __attribute__((aligned(16))) unsigned char L_bytes[GEOM == GEOM_INTRA ? ROWLDS_INTRA_BYTES : sizeof(RowLds)];
     RowLds &L = *reinterpret_cast<RowLds *>(L_bytes);
-    const int wv = WAVES == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;     /* which wavefront of the workgroup */
+    const int wv = WAVES >= 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;     /* which wavefront of the workgroup */
 #ifdef H264E_LDS_PAD
     /* diagnostic build (Makefile `halfres`): extra LDS per workgroup so that fewer workgroups fit a CU -- what single-stream throughput
      * does when the resident rows are halved with the macroblock latency unchanged (the price of a multi-wave workgroup) */
@@ -248,7 +257,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
     if (row < T.first_row) return;          /* kept from the previous encode of this frame (its counter already says complete) */
     if (job == 0 && row == G.test_stall_row) return;    /* fault injection: a producer that never publishes (tests/test_gpu_failures.py) */
     if (wv == 0) row_begin(L, G, C, T, row);
-    if (WAVES == 2) __syncthreads();         /* the one workgroup barrier: both wavefronts see the row's tables and initial state */
+    if (WAVES >= 2) __syncthreads();         /* the one workgroup barrier: all wavefronts see the row's tables and initial state */
     const RowTask RT = rowtask_load(T);      /* the task's hot fields, once, in registers */
     int row0 = 0, row1 = G.nmby;            /* the slice (row band) this row belongs to */
     for (int k = 0; k < T.nslices; k++)
@@ -303,7 +312,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
             }
             /* two waves: macroblock x uses the hand-off buffer of x - 2, which the reconstruction wave must have left behind */
             STAMP(L, 13);
-            if (WAVES == 2 && !st && x >= 2) st = lds_wait(&L.f_wdone, x - 1, &L.f_stop);
+            if (WAVES >= 2 && !st && x >= 2) st = lds_wait(&L.f_wdone, x - 1, &L.f_stop);
             STAMP(L, 23);
             if (!st) row_prefetch<GEOM>(L, G, RT, row, x);
             STAMP(L, 0);
@@ -313,20 +322,20 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
              * the rest of the record, which this row's reconstruction wave waits for */
             if (!st && seen < need)
             {
-                st = poll_progress(C.progress + (WAVES == 2 ? G.nmby : 0) + (row - 1), need, seen, G.spin_limit);
+                st = poll_progress(C.progress + (WAVES >= 2 ? G.nmby : 0) + (row - 1), need, seen, G.spin_limit);
                 if (!st) consumer_acquire();
             }
             STAMP(L, 13);
-            if (!st) load_top<WAVES == 2 ? LOAD_TOP_MV : LOAD_TOP_ALL>(L, L.mb[x & 1], G, C.bottom + (size_t)(row - 1)*G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, row > row0);
+            if (!st) load_top<WAVES >= 2 ? LOAD_TOP_MV : LOAD_TOP_ALL>(L, L.mb[x & 1], G, C.bottom + (size_t)(row - 1)*G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, row > row0);
             /* two waves: the search of x starts from the predictor context the decision of x - 1 leaves behind */
             STAMP(L, 0);
-            if (WAVES == 2 && !st && x >= 1) st = lds_wait(&L.f_decided, x, &L.f_stop);
+            if (WAVES >= 2 && !st && x >= 1) st = lds_wait(&L.f_decided, x, &L.f_stop);
             STAMP(L, 6);
             if (st)
             {
                 /* stop: leave poison in this row's counter so everything behind it stops too (-1 failure, -2 abort); with two waves the
                  * reconstruction wave is the one that publishes, so it also leaves the poison (after what it is publishing right now) */
-                if (WAVES == 2) { flag_set(&L.f_stop, st); return; }
+                if (WAVES >= 2) { flag_set(&L.f_stop, st); return; }
                 if (LANE == 0)
                 {
                     if (st == -1) *errflag = 1;
@@ -335,13 +344,14 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
                 return;
             }
             if (WAVES == 1) row_step<GEOM>(L, G, C, RT, row, x, row0, row1);
-            else mb_search<GEOM>(L, L.mb[x & 1], G, RT, row, x, row0, SearchSignals{ &L, x + 1 });
+            else mb_search<GEOM>(L, L.mb[x & 1], G, RT, row, x, row0, SearchSignals{ &L, x + 1, WAVES == 3 });
+            if (WAVES == 3 && uni(flag_get(&L.f_stop))) return;         /* stopped while waiting for the helper wave */
             {
                 /* a far reference read of this macroblock waited in vain (rv_wait_rect): what it encoded is not trustworthy */
                 const int ff = uni(L.far_fail[0]) | (WAVES == 1 ? uni(L.far_fail[1]) : 0);
                 if (ff)
                 {
-                    if (WAVES == 2) { flag_set(&L.f_stop, ff < -2 ? -2 : ff); return; }
+                    if (WAVES >= 2) { flag_set(&L.f_stop, ff < -2 ? -2 : ff); return; }
                     if (LANE == 0)
                     {
                         if (ff == -1) *errflag = 1;
@@ -350,7 +360,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
                     return;
                 }
             }
-            if (WAVES == 2) { flag_set(&L.f_inter, x + 1); STAMP(L, 14); continue; }
+            if (WAVES >= 2) { flag_set(&L.f_inter, x + 1); STAMP(L, 14); continue; }
             /* producer: every handed-off byte was stored write-through (sc1, wave.h cstore*): drain them, then the counter --
              * no agent-scope release (L2 write-back) needed */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -358,13 +368,45 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
             if (LANE == 0) __hip_atomic_store(my_progress, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             STAMP(L, 14);
         }
-        if (WAVES == 2)
+        if (WAVES >= 2)
         {
 #ifdef H264E_STAMPS
             if (LANE < 32 && C.prof) atomicAdd(C.prof + LANE, L.prof[0][LANE]);
 #endif
             return;
         }
+    } else if (WAVES == 3 && wv == 2)
+    {
+        /* ---- the helper wave of the three-wave variant (launches of one or a few frames, where only the latency counts and the chip
+         * is empty): searches the 8x8 partition type of macroblock x when the search wave asks for it */
+        for (int x = 0; x < G.nmbx; x++)
+        {
+            int req = 0, st = 0;
+            for (unsigned spins = 0;; spins++)
+            {
+                if (uni(flag_get(&L.f_t3req)) >= x + 1) { req = 1; break; }         /* (asked for first: a request for x precedes f_inter of x) */
+                if (uni(flag_get(&L.f_inter)) >= x + 1) break;                      /* the search wave is done with x without asking */
+                if (uni(flag_get(&L.f_stop))) { st = 1; break; }
+                if (spins > LDS_SPIN_LIMIT) { flag_set(&L.f_stop, -1); st = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (st) return;
+            if (!req) continue;
+            MbCtx m;
+            mb_ctx_init<GEOM>(m, L, G, RT, row, x, row0, 2);
+            const rect_t lim = { uni(L.t3_lim[0]), uni(L.t3_lim[1]), uni(L.t3_lim[2]), uni(L.t3_lim[3]) };
+            const mv32 mv_best = (mv32)uni(L.t3_mv_best);
+            const int sad_best = uni(L.t3_sad_best);
+            GRP_EACH(t)
+            {
+                if (t == 3) search_type(L, L.mb[x & 1], m, 3, mv_best, sad_best, lim, 0);
+            }
+            wave_sync();
+            const int ff = uni(L.far_fail[2]);
+            if (ff) { flag_set(&L.f_stop, ff < -2 ? -2 : ff); return; }
+            flag_set(&L.f_t3done, x + 1);
+        }
+        return;
     } else
     {
         /* ---- the reconstruction wave of the two-wave pipeline: intra candidates + decision of x, then transform / CAVLC / deblocking /
@@ -471,8 +513,8 @@ __global__ void h264e_ssd_kernel(const uint8_t *clip, size_t frame_bytes, int wi
 
 /* ------------------------------------------------------------------ launches (what h264e_pool.h calls) */
 
-/* variant: 0 = intra frames only (one wave per row, 4 per SIMD), 1 = one wave per row, 2 = two waves per row (3 per SIMD), 4 = two waves
- * per row at 4 per SIMD */
+/* variant: 0 = intra frames only (one wave per row, 4 per SIMD), 1 = one wave per row, 2 = two waves per row (3 per SIMD), 3 = three waves
+ * per row (search | reconstruction | 8x8 search helper), 4 = two waves per row at 4 per SIMD */
 static void bk_launch_mb(const h264e_geom_t &G, int narrow, int variant, unsigned nblocks, const h264e_frame_task_t *td, const uint32_t *od, hipStream_t st)
 {
     const dim3 grid(nblocks);
@@ -481,6 +523,10 @@ static void bk_launch_mb(const h264e_geom_t &G, int narrow, int variant, unsigne
     {
         if (narrow) hipLaunchKernelGGL((h264e_mb_kernel<GEOM_NARROW, 2, 4>), grid, dim3(128), 0, st, G, td, od);
         else hipLaunchKernelGGL((h264e_mb_kernel<GEOM_WIDE, 2, 4>), grid, dim3(128), 0, st, G, td, od);
+    } else if (variant == 3)
+    {
+        if (narrow) hipLaunchKernelGGL((h264e_mb_kernel<GEOM_NARROW, 3, 2>), grid, dim3(192), 0, st, G, td, od);
+        else hipLaunchKernelGGL((h264e_mb_kernel<GEOM_WIDE, 3, 2>), grid, dim3(192), 0, st, G, td, od);
     } else if (variant == 2)
     {
         if (narrow) hipLaunchKernelGGL((h264e_mb_kernel<GEOM_NARROW, 2, H264E_WPE2>), grid, dim3(128), 0, st, G, td, od);

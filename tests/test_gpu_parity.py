@@ -172,7 +172,7 @@ def test_1080p_long_clip_is_invariant(P):
     assert outs[0] == outs[1] == outs[2] == outs[3]
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4])
+@pytest.mark.parametrize("waves", [1, 2, 3, 4])
 @pytest.mark.parametrize("name,w,h,n,gop,slices", [("synth", 352, 288, 9, 4, 0), ("pan", 640, 368, 6, 30, 3), ("scene", 200, 120, 7, 7, 0)])
 def test_every_kernel_variant_matches_oracle(P, monkeypatch, waves, name, w, h, n, gop, slices):
     """the macroblock kernel exists in variants chosen per launch (h264e_kernels.hip bk_launch_mb): one wave per row, two waves per row
