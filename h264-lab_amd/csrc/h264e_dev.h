@@ -8,7 +8,8 @@
  *               replicated borders (h264-lab.h:2232-2248, 3580-3596)
  *   bottom      one 64-byte record per macroblock: what the row below needs from it
  *   pend        per macroblock: its bottom lines until the row below has filtered them (h264e_mbpend_t)
- *   progress    one counter per macroblock row: macroblocks finished in that row (wavefront hand-off)
+ *   progress    one counter per macroblock row: macroblocks finished in that row (wavefront hand-off), followed by one `decided`
+ *               counter per row: macroblocks whose vectors are final and stored (what the search wave of the row below waits for)
  *   rowbits     one bit buffer per macroblock row (MSB-first 32-bit words)
  *   mbrec       per macroblock {mv[0], type, used-candidates} for the mv_clusters validation
  *   arena       finished slice RBSPs, written by the frame's finalizer workgroup
@@ -136,7 +137,7 @@ typedef struct
     uint8_t *rec[2][3];
     h264e_mbbottom_t *bottom;
     h264e_mbpend_t *pend;               /* [nmb] */
-    int *progress;
+    int *progress;                      /* [2*nmby]: rows' progress counters, then their `decided` counters */
     uint32_t *rowbits;
     h264e_rowmeta_t *rowmeta;
     h264e_mbrec_t *mbrec;               /* [frame slots][nmb] */
