@@ -66,12 +66,13 @@ struct RowLds
     int far_reads[3];                               /* reference accesses of this row that left the valid window (search / reconstruction side / 8x8 search helper) */
     int far_fail[3];                                /* a dynamic wait behind such an access gave up (enc_kernels.h rv_wait_rect): -1 expired, -2 producer aborted */
     int16_t slice_row[H264E_MAX_SLICES + 2];       /* this frame's slice start rows (copy of the task's) */
-    unsigned long long prof[3][32], prof_last[3], prof_c0, prof_w0;     /* -DH264E_STAMPS diagnostic build only */
+    unsigned long long prof[4][32], prof_last[4], prof_c0, prof_w0;     /* -DH264E_STAMPS diagnostic build only */
     /* hand-off words of the two-wave pipeline (h264e_kernels.hip): monotonic counters "macroblocks done" per stage, and a stop code */
     int f_noskip, f_bound, f_inter, f_decided, f_wdone, f_stop;
     int early_bound;                                /* an upper bound of the inter cost, known right after the candidate evaluation (f_bound) */
     /* three waves per row (latency-bound launches): the search wave hands the 8x8 partition type to a helper wave */
     int f_t3req, f_t3done;                          /* macroblocks for which the 8x8 search was requested / is done */
+    int f_front, d_type[2];                         /* four waves per row: macroblocks whose mb_recon_front is done (the fourth wave takes mb_recon_back), their final types */
     int t3_sad_best, t3_lim[4];                     /* the request: start cost, vector limits (the start vector below) */
     mv32 t3_mv_best;
 

@@ -63,7 +63,7 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
     L.bw.cap = (uint32_t)G.row_words;
     L.bw.buf = C.rowbits + (size_t)row*G.row_words;
     L.skip_run = 0; L.lead_skips = 0; L.coded_any = 0; L.far_reads[0] = L.far_reads[1] = L.far_reads[2] = 0; L.far_fail[0] = L.far_fail[1] = L.far_fail[2] = 0;
-    L.f_noskip = L.f_bound = L.f_inter = L.f_decided = L.f_wdone = L.f_stop = 0; L.early_bound = 0; L.f_t3req = L.f_t3done = 0;
+    L.f_noskip = L.f_bound = L.f_inter = L.f_decided = L.f_wdone = L.f_stop = 0; L.early_bound = 0; L.f_t3req = L.f_t3done = L.f_front = 0;
     WAVE_FOR(l) { if (l <= H264E_MAX_SLICES) L.slice_row[l] = l <= T.nslices ? T.slice_row[l] : (int16_t)0x7fff; }
     WAVE_FOR(l)
     {
@@ -74,7 +74,7 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
     df_tab_load(L.dftab);
     L.qconst[0] = k_lambda_mv_q4[T.qp]; L.qconst[1] = k_lambda_q4[T.qp]; L.qconst[2] = k_skip_thr_inter[T.qp];
     L.qconst[3] = k_skip_thr_i4x4[T.qp]; L.qconst[4] = k_lambda_i4_q4[T.qp]; L.qconst[5] = k_lambda_i16_q4[T.qp];
-    for (int i = 0; i < 32; i++) L.prof[0][i] = L.prof[1][i] = 0;
+    for (int i = 0; i < 32; i++) L.prof[0][i] = L.prof[1][i] = L.prof[2][i] = L.prof[3][i] = 0;
     L.prof_last[0] = L.prof_last[1] = 0;
     PROF_ROW_BEGIN(L);
     wave_sync();
@@ -242,6 +242,7 @@ struct InterIsThere
     DEVM bool wait_bound_or_ready() const { return true; }
     DEVM bool wait_ready() const { return true; }
     DEVM int early_bound() const { return 0x7fffffff; }
+    DEVM bool before_decide() const { return true; }
 };
 
 /* reconstruction side, first half: the intra candidates and the final decision.  The intra candidates do not need the inter decision
@@ -282,8 +283,9 @@ template <class P> DEV bool mb_intra_decide(RowLds &L, MbBuf &B, MbCtx &m, const
         if (!pol.wait_ready()) return false;
         STAMP(L, 16);           /* two waves: waited for the inter decision */
         m.type = uni(B.type); m.cost = uni(B.cost);
+        if (!pol.before_decide()) return false;
         if (m.type >= 0) intra_merge(L, B, m, cost16, cost4, nz4);
-    }
+    } else if (!pol.before_decide()) return false;
     m.used_cand = uni(B.used_cand); m.mv_skip_pred = (mv32)uni(B.mv_skip_pred);
     mb_decide(L, B, m);
     return true;
@@ -291,10 +293,12 @@ template <class P> DEV bool mb_intra_decide(RowLds &L, MbBuf &B, MbCtx &m, const
 
 /* reconstruction side, second half */
 struct NoHook { DEVM void operator()() const {} };
-template <int GEOM, class HOOK> DEV void mb_recon_write(RowLds &L, MbBuf &B, MbCtx &m, const h264e_geom_t &G, const ChainG &C, const RowTask &T, int row, int x, int row0, int row1, HOOK after_prediction)
+/* ... in two parts, because a fourth wave can take the second one (h264e_kernels.hip, the latency variant): mb_recon_front = chroma
+ * prediction, mb_write, the validation record, the unfiltered edges the next macroblock's intra prediction needs; mb_recon_back =
+ * deblocking and every store of the macroblock (picture, pending lines, the record for the row below) -- nothing the front part of the
+ * NEXT macroblock needs before its mb_decide */
+template <int GEOM, class HOOK> DEV void mb_recon_front(RowLds &L, MbBuf &B, MbCtx &m, const h264e_geom_t &G, const ChainG &C, const RowTask &T, int row, int x, int row0, int row1, HOOK after_prediction)
 {
-    const bool have_top = row > row0;
-    GLOBAL_AS h264e_mbbottom_t *rowrec = C.bottom + (size_t)row*G.nmbx;
     if (GEOM == GEOM_INTRA || m.type >= 5) wave_pred_chroma(L.pred_c, L.pix_left + 16, B.pix_top + 16, m.avail, m.i16_mode);
     else predict_chroma_inter(B, m, L.pred_c);
     after_prediction();             /* two waves per row: the `decided` counter (h264e_kernels.hip) */
@@ -337,6 +341,14 @@ template <int GEOM, class HOOK> DEV void mb_recon_write(RowLds &L, MbBuf &B, MbC
     }
     wave_sync();
 
+}
+
+template <int GEOM> DEV void mb_recon_back(RowLds &L, MbBuf &B, MbCtx &m, const h264e_geom_t &G, const ChainG &C, const RowTask &T, int row, int x, int row0, int row1)
+{
+    const bool have_top = row > row0;
+    GLOBAL_AS h264e_mbbottom_t *rowrec = C.bottom + (size_t)row*G.nmbx;
+    uint8_t *ty = L.ytile + 4*YT_STRIDE + 4;
+    uint8_t *tc0 = L.ctile[0] + 2*CT_STRIDE + 2, *tc1 = L.ctile[1] + 2*CT_STRIDE + 2;
     /* deblock on the LDS tiles: left strips from LDS (previous macroblock), top strips from the pending lines of the
      * row above (h264e_mbpend_t) */
     const int W = G.W, Wc = G.W >> 1;
@@ -470,6 +482,12 @@ template <int GEOM, class HOOK> DEV void mb_recon_write(RowLds &L, MbBuf &B, MbC
 #ifndef H264E_TYPES_PROBE
     PCOUNT(L, 20 + (m.type < 0 ? 0 : m.type < 5 ? 1 : 2));
 #endif
+}
+
+template <int GEOM, class HOOK> DEV void mb_recon_write(RowLds &L, MbBuf &B, MbCtx &m, const h264e_geom_t &G, const ChainG &C, const RowTask &T, int row, int x, int row0, int row1, HOOK after_prediction)
+{
+    mb_recon_front<GEOM>(L, B, m, G, C, T, row, x, row0, row1, after_prediction);
+    mb_recon_back<GEOM>(L, B, m, G, C, T, row, x, row0, row1);
 }
 
 /* the three phases one after the other: one wavefront per row, and the emulation */

@@ -81,6 +81,9 @@ struct InterFromSearchWave
 {
     RowLds *L;
     int need;
+    bool back_wave;     /* four waves per row: mb_recon_back of the previous macroblock runs on the fourth wave */
+    /* ... which reads the deblocking inputs mb_decide is about to overwrite: wait until it is done with macroblock need - 2 */
+    DEVM bool before_decide() const { return !back_wave || need < 2 || lds_wait(&L->f_wdone, need - 1, &L->f_stop) == 0; }
     DEVM bool ready() const { return uni(flag_get(&L->f_inter)) >= need; }
     DEVM bool wait_ready() const { return lds_wait(&L->f_inter, need, &L->f_stop) == 0; }
     DEVM int early_bound() const { return uni(flag_get(&L->f_bound)) >= need ? uni(L->early_bound) : 0x7fffffff; }
@@ -344,8 +347,8 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
                 return;
             }
             if (WAVES == 1) row_step<GEOM>(L, G, C, RT, row, x, row0, row1);
-            else mb_search<GEOM>(L, L.mb[x & 1], G, RT, row, x, row0, SearchSignals{ &L, x + 1, WAVES == 3 });
-            if (WAVES == 3 && uni(flag_get(&L.f_stop))) return;         /* stopped while waiting for the helper wave */
+            else mb_search<GEOM>(L, L.mb[x & 1], G, RT, row, x, row0, SearchSignals{ &L, x + 1, WAVES >= 3 });
+            if (WAVES >= 3 && uni(flag_get(&L.f_stop))) return;         /* stopped while waiting for the helper wave */
             {
                 /* a far reference read of this macroblock waited in vain (rv_wait_rect): what it encoded is not trustworthy */
                 const int ff = uni(L.far_fail[0]) | (WAVES == 1 ? uni(L.far_fail[1]) : 0);
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
 #endif
             return;
         }
-    } else if (WAVES == 3 && wv == 2)
+    } else if (WAVES >= 3 && wv == 2)
     {
         /* ---- the helper wave of the three-wave variant (launches of one or a few frames, where only the latency counts and the chip
          * is empty): searches the 8x8 partition type of macroblock x when the search wave asks for it */
@@ -406,6 +409,34 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
             if (ff) { flag_set(&L.f_stop, ff < -2 ? -2 : ff); return; }
             flag_set(&L.f_t3done, x + 1);
         }
+#ifdef H264E_STAMPS
+        if (LANE < 32 && C.prof) atomicAdd(C.prof + LANE, L.prof[2][LANE]);
+#endif
+        return;
+    } else if (WAVES == 4 && wv == 3)
+    {
+        /* ---- the fourth wave of the latency variant: deblocking and every store of macroblock x (mb_recon_back) while the
+         * reconstruction wave is already at the intra candidates of x + 1; owns the row's progress counter */
+        for (int x = 0; x < G.nmbx; x++)
+        {
+            const int st = lds_wait(&L.f_front, x + 1, &L.f_stop);
+            if (st)
+            {
+                if (LANE == 0) __hip_atomic_store(my_progress, st == -2 ? -2 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        /* the row is being stopped: poison for everything behind it */
+                return;
+            }
+            MbCtx m;
+            mb_ctx_init<GEOM>(m, L, G, RT, row, x, row0, 1);
+            m.type = uni(L.d_type[x & 1]);
+            mb_recon_back<GEOM>(L, L.mb[x & 1], m, G, C, RT, row, x, row0, row1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (LANE == 0) __hip_atomic_store(my_progress, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag_set(&L.f_wdone, x + 1);
+        }
+#ifdef H264E_STAMPS
+        if (LANE < 32 && C.prof) atomicAdd(C.prof + LANE, L.prof[3][LANE]);
+#endif
         return;
     } else
     {
@@ -432,20 +463,27 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
             if (!ff)
             {
                 load_top<LOAD_TOP_REST>(L, B, G, C.bottom + (size_t)(row - 1)*G.nmbx, C.pend + (size_t)(row - 1)*G.nmbx, x, row > row0);
-                if (!mb_intra_decide(L, B, m, RT, InterFromSearchWave{ &L, x + 1 })) ff = uni(flag_get(&L.f_stop));
+                if (!mb_intra_decide(L, B, m, RT, InterFromSearchWave{ &L, x + 1, WAVES == 4 })) ff = uni(flag_get(&L.f_stop));
                 else
                 {
                     flag_set(&L.f_decided, x + 1);
                     /* the vectors of this macroblock's bottom row, for the search of the row below: on their way while the chroma
                      * prediction runs, published before the transform starts */
                     WAVE_FOR(l) { if (l < 4) cstore32((gu8 *)(rowrec + x) + 32 + 4*l, (uint32_t)B.mv_top[l]); }
-                    mb_recon_write<GEOM>(L, B, m, G, C, RT, row, x, row0, row1, [&]() {
+                    const auto publish_decided = [&]() {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __builtin_amdgcn_wave_barrier();
                         if (LANE == 0) __hip_atomic_store(my_decided, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    });
+                    };
+                    if (WAVES == 4)
+                    {
+                        /* deblocking and the macroblock's stores go to the fourth wave; this one moves on to the intra candidates of x + 1 */
+                        mb_recon_front<GEOM>(L, B, m, G, C, RT, row, x, row0, row1, publish_decided);
+                        L.d_type[x & 1] = m.type;
+                    } else mb_recon_write<GEOM>(L, B, m, G, C, RT, row, x, row0, row1, publish_decided);
                     ff = uni(L.far_fail[1]);
                     if (ff) { ff = ff < -2 ? -2 : ff; flag_set(&L.f_stop, ff); }
+                    else if (WAVES == 4) flag_set(&L.f_front, x + 1);
                 }
             }
             if (ff)
@@ -454,16 +492,19 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
                 {
                     if (ff == -1) *errflag = 1;
                     __hip_atomic_store(my_decided, ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(my_progress, ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (WAVES != 4) __hip_atomic_store(my_progress, ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* (four waves: the fourth one owns the progress counter, poison included) */
                 }
                 return;
             }
+            if (WAVES == 4) { STAMP(L, 14); continue; }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             if (LANE == 0) __hip_atomic_store(my_progress, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             flag_set(&L.f_wdone, x + 1);
             STAMP(L, 14);
         }
+        /* four waves: the row ends when the fourth wave has stored the last macroblock */
+        if (WAVES == 4 && lds_wait(&L.f_wdone, G.nmbx, &L.f_stop)) return;
     }
     row_end(L, G, C, row);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -513,8 +554,8 @@ __global__ void h264e_ssd_kernel(const uint8_t *clip, size_t frame_bytes, int wi
 
 /* ------------------------------------------------------------------ launches (what h264e_pool.h calls) */
 
-/* variant: 0 = intra frames only (one wave per row, 4 per SIMD), 1 = one wave per row, 2 = two waves per row (3 per SIMD), 3 = three waves
- * per row (search | reconstruction | 8x8 search helper), 4 = two waves per row at 4 per SIMD */
+/* variant: 0 = intra frames only (one wave per row, 4 per SIMD), 1 = one wave per row, 2 = two waves per row (3 per SIMD), 3 = the latency variant: four
+ * waves per row (search | reconstruction | 8x8 search helper | deblocking and stores), 4 = two waves per row at 4 per SIMD */
 static void bk_launch_mb(const h264e_geom_t &G, int narrow, int variant, unsigned nblocks, const h264e_frame_task_t *td, const uint32_t *od, hipStream_t st)
 {
     const dim3 grid(nblocks);
@@ -525,8 +566,8 @@ static void bk_launch_mb(const h264e_geom_t &G, int narrow, int variant, unsigne
         else hipLaunchKernelGGL((h264e_mb_kernel<GEOM_WIDE, 2, 4>), grid, dim3(128), 0, st, G, td, od);
     } else if (variant == 3)
     {
-        if (narrow) hipLaunchKernelGGL((h264e_mb_kernel<GEOM_NARROW, 3, 2>), grid, dim3(192), 0, st, G, td, od);
-        else hipLaunchKernelGGL((h264e_mb_kernel<GEOM_WIDE, 3, 2>), grid, dim3(192), 0, st, G, td, od);
+        if (narrow) hipLaunchKernelGGL((h264e_mb_kernel<GEOM_NARROW, 4, 2>), grid, dim3(256), 0, st, G, td, od);
+        else hipLaunchKernelGGL((h264e_mb_kernel<GEOM_WIDE, 4, 2>), grid, dim3(256), 0, st, G, td, od);
     } else if (variant == 2)
     {
         if (narrow) hipLaunchKernelGGL((h264e_mb_kernel<GEOM_NARROW, 2, H264E_WPE2>), grid, dim3(128), 0, st, G, td, od);

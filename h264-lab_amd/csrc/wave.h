@@ -382,7 +382,7 @@ DEV uint64_t v64_nonzero_ballot(const V64 &a) { return __ballot(a.v != 0); }
 #define PTIC() unsigned long long tic_ = __builtin_readcyclecounter()
 #define PTOC(L, id) do { (L).prof[PROF_W][id] += __builtin_readcyclecounter() - tic_; } while (0)
 #define PROF_ROW_BEGIN(L) do { (L).prof_c0 = __builtin_readcyclecounter(); (L).prof_w0 = wall_clock64(); } while (0)     /* shader-clock cycles vs constant 100 MHz clock: effective frequency */
-#define PROF_ROW_SYNC(L) do { (L).prof_last[0] = (L).prof_last[1] = __builtin_readcyclecounter(); } while (0)
+#define PROF_ROW_SYNC(L) do { (L).prof_last[0] = (L).prof_last[1] = (L).prof_last[2] = (L).prof_last[3] = __builtin_readcyclecounter(); } while (0)
 #define PROF_ROW_END(L, C) do { (L).prof[PROF_W][28] = __builtin_readcyclecounter() - (L).prof_c0; (L).prof[PROF_W][29] = wall_clock64() - (L).prof_w0; wave_sync(); \
                                 if (LANE < 32 && (C).prof) atomicAdd((C).prof + LANE, (L).prof[PROF_W][LANE]); } while (0)
 #else

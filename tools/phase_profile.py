@@ -35,7 +35,7 @@ def main():
     tot = sum(t[i] for i in ORDER)
     print("%dx%d %d frames gop %d: %d MBs (skip %d, inter %d, intra %d); mb kernel %.1f ms over %d launches; H264E_WAVES=%s" %
           (w, h, frames, gop, nmb, t[20], t[21], t[22], st.mb_kernel_ms, st.kernel_launches, os.environ.get("H264E_WAVES", "auto")))
-    print("S = search side (with two waves per row: the search wave), R = reconstruction side (the reconstruction wave)")
+    print("S = search side (with two waves per row: the search wave), R = reconstruction side (the reconstruction wave); with H264E_WAVES=3 (four waves per row)\nthe 8x8 search helper adds to the S search lines and the deblock/store wave owns 'ctx save + deblock + stores'")
     print("%-58s %12s %8s" % ("phase", "cycles/MB", "share"))
     for i in ORDER:
         print("%-58s %12.0f %7.1f%%" % (NAMES[i], t[i] / nmb, 100.0 * t[i] / tot))
