@@ -304,7 +304,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         if (getenv("H264E_TEST_UPLOAD_FAIL_AT")) p->test_upload_fail_at = atoi(getenv("H264E_TEST_UPLOAD_FAIL_AT"));
     }
     p->frame_bytes = (size_t)width*height*3/2;
-    p->waves = getenv("H264E_WAVES") ? atoi(getenv("H264E_WAVES")) : 0;                  /* 1 / 2: forced (A-B measurements); else chosen per launch */
+    p->waves = getenv("H264E_WAVES") ? atoi(getenv("H264E_WAVES")) : 0;                  /* 1 / 2 / 3 / 4: forced (A-B measurements, tests); else chosen per launch */
     if (p->waves != 1 && p->waves != 2 && p->waves != 3 && p->waves != 4) p->waves = 0;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -901,8 +901,8 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     /* measured with the final register allocation (gpurun_out/r3_lane4): 4 per SIMD wins wherever a launch offers enough rows to fill the
      * chip (8 slices 20.6 -> 23.3 M MB/s, 8K 6.6 -> 9.1 M, 4K 14.8 -> 15.3 M, 1080p single slice 9.56 -> 9.61 M); launches of a few frames
      * (rate control, the frame-at-a-time API) are pure latency and keep the 3-per-SIMD kernel with its fewer spills (10.5 vs 10.9 ms) */
-    /* (... and 3 the three-wave kernel -- the 8x8 partition search on a helper wave: launches of one or a few frames, where the chip is
-     * empty and only the macroblock latency counts: the frame-at-a-time API) */
+    /* (... and 3 the latency variant -- four waves per row: the 8x8 partition search and the deblocking + stores on waves of their own:
+     * launches of one or a few frames, where the chip is empty and only the macroblock latency counts: the frame-at-a-time API) */
     const int waves = p->waves ? p->waves : all_intra ? 0 : (njobs*G.nmby >= 1536) ? 4 : (njobs*G.nmby <= 512) ? 3 : 2;
     (void)max_slices;
     if (p->group)

@@ -175,8 +175,9 @@ def test_1080p_long_clip_is_invariant(P):
 @pytest.mark.parametrize("waves", [1, 2, 3, 4])
 @pytest.mark.parametrize("name,w,h,n,gop,slices", [("synth", 352, 288, 9, 4, 0), ("pan", 640, 368, 6, 30, 3), ("scene", 200, 120, 7, 7, 0)])
 def test_every_kernel_variant_matches_oracle(P, monkeypatch, waves, name, w, h, n, gop, slices):
-    """the macroblock kernel exists in variants chosen per launch (h264e_kernels.hip bk_launch_mb): one wave per row, two waves per row
-    at 3 and at 4 waves per SIMD (H264E_WAVES forces one; all-intra launches always take the intra-only kernel).  The decisions must
+    """the macroblock kernel exists in variants chosen per launch (h264e_kernels.hip bk_launch_mb): one wave per row (H264E_WAVES=1), two
+    waves per row at 3 and at 4 waves per SIMD (2, 4), the four-wave latency variant (3); all-intra launches always take the intra-only
+    kernel.  The decisions must
     not depend on the variant: every one, both window geometries, with and without row-band slices, against the oracle"""
     monkeypatch.setenv("H264E_WAVES", str(waves))
     c = clips.make(name, w, h, n)
