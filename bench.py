@@ -37,13 +37,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # algorithmic bytes per macroblock: input 384 B; P frames also read the co-located reference
 # (384 B); every frame writes 384 B of reconstruction
 READ_I, READ_P, WRITE = 384, 768, 384
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 
 def _pmc_traffic():
     """HBM bytes per h264e_mb_kernel launch from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate
     runs of this same command; the json says how they were taken).  STATIC: read from profiles/, not measured in this run."""
-    for tag in (PROFILE_TAG, "r02", "r01"):
+    for tag in (PROFILE_TAG, "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)) as f:
                 return json.load(f)["bytes_per_launch"], "static_from_profiles/%s_pmc_traffic.json" % tag
@@ -54,7 +54,7 @@ def _pmc_traffic():
 
 def _issue_counters():
     """SQ instruction counters of the committed profile (tools/pmc_insts.sh), for the issue roofline; static like the traffic"""
-    for tag in (PROFILE_TAG, "r02", "r01"):
+    for tag in (PROFILE_TAG, "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_sq_counters.json" % tag)) as f:
                 return json.load(f), "static_from_profiles/%s_sq_counters.json" % tag
@@ -72,6 +72,18 @@ def _golden_md5(w, h, frames, gop, qp):
                     return g["md5"]
     except Exception:
         pass
+    return None
+
+
+def _single_gpu_line():
+    """the committed one-GPU bench line of this build (profiles/), for the N > 1 lines to show beside their own time.  STATIC."""
+    for tag in (PROFILE_TAG, "r03"):
+        try:
+            with open(os.path.join(ROOT, "profiles", "%s_bench_line.json" % tag)) as f:
+                d = json.load(f)
+            return {"ms_per_step": d["ms_per_step"], "value": d["value"], "source": "static_from_profiles/%s_bench_line.json" % tag}
+        except Exception:
+            continue
     return None
 
 
@@ -191,6 +203,7 @@ def multi_slice_pass(P, frames, w, h, gop, slices=8):
     except Exception:
         pass
     return {"slices": slices, "value": frames * nmb / dt, "unit": "macroblocks/s", "fps": frames / dt, "relaunches": st.reencoded_gops,
+            "spin_relaunches": st.spin_relaunches, "processed_mb": st.processed_mbs, "discarded_mb": st.processed_mbs - st.delivered_mbs,
             "stream_md5": md5, "parity_full_stream": (md5 == want) if want else None,
             "note": "a different (multi-slice) bitstream: the reference built with -DH264E_MAX_THREADS and run with --threads %d; not the headline" % slices}
 
@@ -214,6 +227,8 @@ def multi_stream_pass(P, frames, w, h, gop, clips=4):
     md5s = [hashlib.md5(r[0]).hexdigest() for r in res]
     return {"clips": clips, "value": clips * frames * nmb / dt, "unit": "macroblocks/s", "fps": clips * frames / dt,
             "parity_full_stream": all(m == want for m in md5s) if want else None, "relaunches": [r[2].reencoded_gops for r in res],
+            "spin_relaunches": [r[2].spin_relaunches for r in res], "processed_mb": [r[2].processed_mbs for r in res],
+            "discarded_mb": [r[2].processed_mbs - r[2].delivered_mbs for r in res],
             "note": "aggregate of %d single-slice streams in one launch group on ONE GPU; every stream md5-checked against the reference; not the headline" % clips}
 
 
@@ -307,12 +322,19 @@ def main():
     t0 = time.time()
     mb_ms = splice_ms = 0.0
     launches = 0
+    spins = relaunches_timed = processed = delivered = 0
+    refill_ms = 0.0
     for _ in range(a.steps):
         out, sizes, st = one_step(True)     # HIP events on the encoder's own stream, read after the step
         if st is not None:
             mb_ms += st.mb_kernel_ms
             splice_ms += st.splice_kernel_ms
             launches += st.kernel_launches
+            spins += st.spin_relaunches
+            relaunches_timed += st.relaunches_timed
+            refill_ms += st.first_frame_ms_after_relaunch
+            processed += st.processed_mbs
+            delivered += st.delivered_mbs
     barrier()
     dt = time.time() - t0
     if dist is not None:
@@ -354,7 +376,15 @@ def main():
                                    (w, h, frames, gop, QP, "ONE stream GOP-sharded over the ranks" if stream_mode else "one clip per rank on 1xMI355X each"),
                        "frames_per_step": frames, "slot_ring_frames": st.chains if st is not None else None, "fps": total_frames / dt,
                        "coded_bytes_per_step": len(out), "relaunches_per_step": (st.reencoded_gops if st is not None else None),
-                       "slices_per_frame": max(a.slices, 1), "shard": a.shard},
+                       "slices_per_frame": max(a.slices, 1), "shard": a.shard,
+                       # event bookkeeping of rank 0's encoder over the timed steps (H264E_clip_stats_t): launches that had to be repeated
+                       # because a bounded in-kernel wait expired (a forward-progress failure a retry would hide: expected 0), what the
+                       # kernel reconstructed against what was delivered, and what a stopped launch costs until frames flow again
+                       "spin_relaunches_per_step": spins / a.steps,
+                       "processed_mb_per_step": processed / a.steps, "discarded_mb_per_step": (processed - delivered) / a.steps,
+                       "discarded_share": ((processed - delivered) / processed) if processed else None,
+                       "ms_to_first_frame_after_relaunch": (refill_ms / relaunches_timed) if relaunches_timed else None,
+                       "relaunches_timed": relaunches_timed},
             # achieved = algorithmic READ bytes (755.2 B/MB at GOP 30) / kernel time; read+write beside it
             "roofline": {"bound": "hbm", "achieved": ach_r, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_r / HBM_PEAK_GBS,
                          "achieved_read_write": ach_rw, "frac_read_write": ach_rw / HBM_PEAK_GBS,
@@ -367,6 +397,14 @@ def main():
             # what actually bounds this kernel: vector-instruction issue.  A wave64 VALU instruction occupies its SIMD for 4 cycles of
             # the counters' clock domain (MI355X_MICROARCH.md: one wave alone issues at most one per 4); 1024 SIMDs.
             line["issue_roofline"] = dict(ic, source=ic_src)
+        if world > 1:
+            # what the N > 1 number means: clips = every rank its own stream (throughput; the driver's scaling run);
+            # stream = GOP blocks of ONE stream, where a single-slice CQP stream re-encodes most blocks (the mv_clusters state is a
+            # never-forgetting counter, SURVEY F3: measured 50 / 75 / 90 % of the frames again at 2 / 4 / 8 blocks, profiles/) and
+            # only row-band multi-slice streams shard exactly.  The committed one-GPU figure stands beside it.
+            line["config"]["shard_mode_note"] = ("one stream per GPU, no exchange: weak scaling by construction" if not stream_mode else
+                                                 "GOP blocks of ONE stream with an 8-byte mv_clusters hand-off per boundary; frames_encoded_again_per_rank says what the speculation cost")
+            line["config"]["single_gpu"] = _single_gpu_line()
         if per_rank is not None:
             line["config"]["per_rank_md5"] = per_rank
         if stream_mode:

@@ -47,7 +47,8 @@ class ClipParam(C.Structure):
 class ClipStats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("upload_ms", "encode_ms", "readback_ms", "assemble_ms", "mb_kernel_ms", "splice_kernel_ms")] + \
                [(n, C.c_int) for n in ("kernel_launches", "chains", "rounds", "reencoded_gops")] + \
-               [("mv_clusters_out", C.c_int32 * 2), ("next_idr_pic_id_state", C.c_int), ("first_frame", C.c_int), ("frames", C.c_int), ("spin_relaunches", C.c_int)]
+               [("mv_clusters_out", C.c_int32 * 2), ("next_idr_pic_id_state", C.c_int), ("first_frame", C.c_int), ("frames", C.c_int), ("spin_relaunches", C.c_int),
+                ("relaunches_timed", C.c_int), ("processed_mbs", C.c_longlong), ("delivered_mbs", C.c_longlong), ("first_frame_ms_after_relaunch", C.c_double)]
 
 
 def lib_path():
@@ -141,6 +142,24 @@ class Encoder:
         if st:
             raise _err(self.L, "H264E_encode status %d" % st)
         return C.string_at(data, n.value)
+
+    def encode_planes(self, y, u, v, frame_type=FRAME_TYPE_DEFAULT):
+        """Three separately allocated planes with any row stride (H264E_io_yuv_t, h264-lab.h:231-237): y, u, v are 2-D uint8 arrays
+        (views into larger buffers are fine) whose LAST axis is contiguous; the row stride is taken from the array.  With
+        const_input_flag = 0 the reconstruction is written back into these arrays (h264-lab.h:6719-6723)."""
+        for a in (y, u, v):
+            assert a.dtype == np.uint8 and a.ndim == 2 and a.strides[1] == 1
+        io = IoYuv((C.c_void_p * 3)(y.ctypes.data, u.ctypes.data, v.ctypes.data), (C.c_int * 3)(y.strides[0], u.strides[0], v.strides[0]))
+        self.rp.frame_type = frame_type
+        data, n = C.c_void_p(), C.c_int()
+        st = self.L.H264E_encode(self.persist, self.scratch, C.byref(self.rp), C.byref(io), C.byref(data), C.byref(n))
+        if st:
+            raise _err(self.L, "H264E_encode status %d" % st)
+        return C.string_at(data, n.value)
+
+    def set_vbv_state(self, vbv_size_bytes, vbv_fullness_bytes):
+        """H264E_set_vbv_state (h264-lab.h:6898-6913)"""
+        self.L.H264E_set_vbv_state(self.persist, vbv_size_bytes, vbv_fullness_bytes)
 
     def close(self):
         if self.persist is not None:

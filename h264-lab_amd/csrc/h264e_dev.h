@@ -192,6 +192,8 @@ typedef struct
     uint8_t *host_rbsp;                 /* host-mapped copy of the RBSP (capacity host_rbsp_cap), or NULL */
     uint32_t host_rbsp_cap;
     h264e_mbrec_t *host_mbrec;          /* host-mapped copy of the macroblock records [nmb], or NULL */
+    unsigned long long *mb_counter;     /* device word of the job's pool: every row adds the macroblocks it reconstructed when it ends or stops (bookkeeping:
+                                           processed vs delivered macroblocks, H264E_clip_stats_t.processed_mbs) */
 } h264e_frame_task_t;
 
 #endif

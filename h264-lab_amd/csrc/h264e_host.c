@@ -746,6 +746,32 @@ int H264E_encode(H264E_persist_t *p, H264E_scratch_t *scratch, const H264E_run_p
     build_qdat(task.qdat, qp, !key);
 
     yuv[0] = in->yuv[0]; yuv[1] = in->yuv[1]; yuv[2] = in->yuv[2];
+    memset(&res, 0, sizeof(res));
+    if (e->param.vbv_size_bytes && e->rc.vbv_bits - opt->desired_frame_bytes*8 > e->param.vbv_size_bytes*8)
+    {
+        /* h264-lab.h:6497-6510 "encode transparent frame on VBV overflow" -- reachable only right after H264E_set_vbv_state (rc_frame_end
+         * clamps the fullness to the VBV size): one slice whose whole payload is a skip run over the picture (written for key frames
+         * too), the reference picture as the reconstruction.  Nothing for the device to do: the pool's reference / reconstruction pair is
+         * simply not swapped, so the next frame predicts from the same picture; mv_clusters do not move (no macroblock was encoded). */
+        uint8_t rb[32];
+        hbits_t b;
+        size_t w;
+        memset(&b, 0, sizeof(b));
+        b.buf = rb;
+        hb_put(&b, 8, (uint32_t)task.hdr_nal);
+        hb_ue(&b, 0);                                                   /* first_mb_in_slice */
+        hb_put(&b, task.hdr_nbits > 32 ? task.hdr_nbits - 32 : 0, (uint32_t)(task.hdr_nbits > 32 ? task.hdr_bits >> 32 : 0));
+        hb_put(&b, task.hdr_nbits > 32 ? 32 : task.hdr_nbits, (uint32_t)task.hdr_bits);
+        hb_ue(&b, (uint32_t)e->seq.nmb);                                /* mb_skip_run = every macroblock */
+        hb_put(&b, 1, 1);                                               /* rbsp_stop_one_bit */
+        if (b.n) hb_put(&b, 8 - b.n, 0);
+        if (out_pos + 2*b.pos + 8 > cap) { snprintf(g_host_err, sizeof(g_host_err), "coded frame does not fit the scratch blob"); return H264E_STATUS_BAD_ARGUMENT; }
+        w = nal_emit(out + out_pos, rb, b.pos);
+        if (opt->nalu_callback) opt->nalu_callback(out + out_pos + 4, (int)(w - 4), opt->nalu_callback_token);
+        out_pos += w;
+        res.all_skipped = 1;
+    } else
+    {
     if (h264e_hip_reset_results(m->pool, 0) || h264e_hip_upload_planes(m->pool, 0, yuv, in->stride)) return H264E_STATUS_BAD_ARGUMENT;
     {
         int32_t run[1][2] = { { e->clusters[0], e->clusters[1] } };
@@ -767,6 +793,7 @@ int H264E_encode(H264E_persist_t *p, H264E_scratch_t *scratch, const H264E_run_p
             return H264E_STATUS_BAD_ARGUMENT;
         }
         out_pos += w;
+    }
     }
 
     rc_frame_end(&e->rc, e->seq.nmb, e->param.vbv_size_bytes, opt->desired_frame_bytes, (int)out_pos, key, res.all_skipped);
@@ -825,6 +852,7 @@ struct H264E_clip_tag
     int narrow_ok;                          /* the picture size allows the narrow geometry at all */
     int wide_until, wide_hold;              /* wide geometry until this frame; length of the next wide spell (doubles when narrow fails again) */
     int launch_base, launch_frames;         /* frames per launch: the pipeline depth after a mis-speculation, growing after clean launches (H264E_clip_open) */
+    int stopped_before;                     /* the previous launch was stopped before its last frame (statistics: the next one pays a pipeline refill) */
     long long far_acc; int far_frames;      /* far reads / frames since the last decision */
     rc_t rcs; int rc_frame, rc_qp;          /* rate control: state, the frame rc_frame_start has run for, its QP */
     int rc_last_bytes[2];                   /* size of the last accepted P / key frame: what a frame still in flight is predicted to weigh */
@@ -840,6 +868,8 @@ struct H264E_clip_tag
     int32_t (*used)[2];                     /* scratch [ring] */
 };
 
+int H264E_struct_size(int which) { return which == 0 ? (int)sizeof(H264E_clip_param_t) : which == 1 ? (int)sizeof(H264E_clip_stats_t) : -1; }
+
 static double now_ms(void)
 {
     struct timespec ts;
@@ -853,7 +883,7 @@ void H264E_clip_rewind(H264E_clip_t *c)
     c->next = 0;
     c->state[0] = c->par.mv_clusters_in[0]; c->state[1] = c->par.mv_clusters_in[1];
     free(c->first_arr); c->first_arr = NULL; c->first_dev = 0;
-    c->first_row = 0; c->have_after = 0; c->recon_floor = 0;
+    c->first_row = 0; c->have_after = 0; c->recon_floor = 0; c->stopped_before = 0;
     /* reference-window geometry (h264e_dev.h): narrow = consecutive frames 4 macroblock steps apart, as long as vectors rarely
      * reach more than 12 samples right / down of their macroblock; wide (7 steps) for the rest of the clip otherwise.  Large
      * pictures already fill the GPU's resident workgroups with the wide geometry: the narrow one only pays below ~12k macroblocks */
@@ -1219,6 +1249,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
         }
         if (nh) c->recon_floor = n;             /* the leaves' slots held the pictures of frames n - K + F .. : gone now */
         stats.rounds++;
+        const int after_stop = c->stopped_before;   /* this launch follows one that was stopped (mis-speculation, rate-control miss): its first frame pays the refill */
         c->have_after = 0;
         const double t_submit = now_ms();
         double t_first = 0, t_last = 0;
@@ -1367,6 +1398,8 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             if (h264e_hip_ssd_frames(c->pool, nvalid, n % c->resident, c->resident, n % K, K, c->ssd_out + 3*(size_t)(n - first))) goto done;
         }
         c->next = n + nvalid;
+        if (after_stop && nvalid) { stats.relaunches_timed++; stats.first_frame_ms_after_relaunch += t_first - t_submit; }
+        c->stopped_before = nvalid < F && !full;
         /* frames per launch: back to the pipeline depth after a mis-speculation, twice as many after a clean launch */
         /* (after an event: twice the frames the stopped launch got through, an estimate of the spacing of the events) */
         if (nvalid < F && !full) c->launch_frames = imin(imax(c->launch_base, 2*nvalid), K - 1);
@@ -1398,6 +1431,11 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
         }
     }
     stats.frames = c->next - first;
+    stats.delivered_mbs = (long long)stats.frames*nmb;
+    {
+        unsigned long long pm = 0;
+        if (!h264e_hip_mb_counter(c->pool, &pm, 1)) stats.processed_mbs = (long long)pm;
+    }
     stats.mv_clusters_out[0] = c->state[0]; stats.mv_clusters_out[1] = c->state[1];
     stats.next_idr_pic_id_state = idr_state ^ (((c->next + G - 1)/G) & 1);
     h264e_hip_profile_read(c->pool, &stats.mb_kernel_ms, &stats.splice_kernel_ms, &stats.kernel_launches);

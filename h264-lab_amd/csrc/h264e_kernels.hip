@@ -267,6 +267,9 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
         if (row >= T.slice_row[k] && row < T.slice_row[k + 1]) { row0 = T.slice_row[k]; row1 = T.slice_row[k + 1]; }
     row0 = uni(row0); row1 = uni(row1);
     GLOBAL_AS int *my_progress = C.progress + row;
+    /* bookkeeping: the wave that reconstructs adds the macroblocks this row got through, once, when the row ends or stops */
+    GLOBAL_AS unsigned long long *mb_counter = (GLOBAL_AS unsigned long long *)uniptr(T.mb_counter);
+    const auto count_mbs = [&](int n) { if (mb_counter && n > 0 && LANE == 0) __hip_atomic_fetch_add(mb_counter, (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 
     if (WAVES == 1 || wv == 0)
     {
@@ -344,6 +347,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
                     if (st == -1) *errflag = 1;
                     __hip_atomic_store(my_progress, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                count_mbs(x);
                 return;
             }
             if (WAVES == 1) row_step<GEOM>(L, G, C, RT, row, x, row0, row1);
@@ -360,6 +364,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
                         if (ff == -1) *errflag = 1;
                         __hip_atomic_store(my_progress, ff < -2 ? -2 : ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    count_mbs(x);
                     return;
                 }
             }
@@ -387,7 +392,14 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
             int req = 0, st = 0;
             for (unsigned spins = 0;; spins++)
             {
-                if (uni(flag_get(&L.f_t3req)) >= x + 1) { req = 1; break; }         /* (asked for first: a request for x precedes f_inter of x) */
+                /* f_t3req is monotonic and carries the macroblock index (+1) of the LATEST request: only an exact match is a request for x.
+                 * A larger value means the search wave finished x without asking and has already asked for a later macroblock -- skip x
+                 * (running the 8x8 search with the context of x and the request data of x + 1 would also write into the hand-off
+                 * buffer the reconstruction wave is reading).  A request for x precedes f_inter of x, and the search wave does not get
+                 * past x while its request is unanswered, so "f_inter >= x + 1 without a request" is final. */
+                const int r3 = uni(flag_get(&L.f_t3req));
+                if (r3 == x + 1) { req = 1; break; }
+                if (r3 > x + 1) break;
                 if (uni(flag_get(&L.f_inter)) >= x + 1) break;                      /* the search wave is done with x without asking */
                 if (uni(flag_get(&L.f_stop))) { st = 1; break; }
                 if (spins > LDS_SPIN_LIMIT) { flag_set(&L.f_stop, -1); st = 1; break; }
@@ -494,6 +506,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
                     __hip_atomic_store(my_decided, ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (WAVES != 4) __hip_atomic_store(my_progress, ff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* (four waves: the fourth one owns the progress counter, poison included) */
                 }
+                count_mbs(x);
                 return;
             }
             if (WAVES == 4) { STAMP(L, 14); continue; }
@@ -504,8 +517,9 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
             STAMP(L, 14);
         }
         /* four waves: the row ends when the fourth wave has stored the last macroblock */
-        if (WAVES == 4 && lds_wait(&L.f_wdone, G.nmbx, &L.f_stop)) return;
+        if (WAVES == 4 && lds_wait(&L.f_wdone, G.nmbx, &L.f_stop)) { count_mbs(G.nmbx); return; }
     }
+    count_mbs(G.nmbx);
     row_end(L, G, C, row);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();

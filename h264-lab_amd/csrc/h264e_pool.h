@@ -37,12 +37,30 @@ static int imin_h(int a, int b) { return a < b ? a : b; }
  * workgroups dispatched before it, which are resident or finished) assumes the launch has the device's wave slots to itself: two
  * such launches side by side can fill the slots with waiting workgroups of one while the workgroups they wait for sit undispatched
  * behind the other's (measured: "bounded spin expired" with 3-4 concurrent clip encoders, tools/multi_clip_probe.py).  A pool takes
- * its device's lock with its first submit and gives it back when its launches have drained (h264e_hip_sync / release / destroy). */
+ * its device's token with its first submit and gives it back when its launches have drained (h264e_hip_sync / release / destroy). */
 #include <pthread.h>
 #define H264E_MAX_DEVICES 64
-static pthread_mutex_t g_device_lock[H264E_MAX_DEVICES] = { PTHREAD_MUTEX_INITIALIZER };
-static pthread_once_t g_device_lock_once = PTHREAD_ONCE_INIT;
-static void device_locks_init(void) { for (int i = 0; i < H264E_MAX_DEVICES; i++) pthread_mutex_init(&g_device_lock[i], 0); }
+/* a token, not a mutex: a launch group takes it on the thread that launches the merged grid and gives it back on whichever member
+ * thread sees the launch drained -- a pthread mutex may only be unlocked by the thread that locked it */
+static pthread_mutex_t g_device_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_device_cv = PTHREAD_COND_INITIALIZER;
+static int g_device_held[H264E_MAX_DEVICES];
+static void device_token_take(int device)
+{
+    const unsigned d = (unsigned)device % H264E_MAX_DEVICES;
+    pthread_mutex_lock(&g_device_mu);
+    while (g_device_held[d]) pthread_cond_wait(&g_device_cv, &g_device_mu);
+    g_device_held[d] = 1;
+    pthread_mutex_unlock(&g_device_mu);
+}
+static void device_token_give(int device)
+{
+    const unsigned d = (unsigned)device % H264E_MAX_DEVICES;
+    pthread_mutex_lock(&g_device_mu);
+    g_device_held[d] = 0;
+    pthread_cond_broadcast(&g_device_cv);
+    pthread_mutex_unlock(&g_device_mu);
+}
 
 /*
  * One encoder PROCESS per device.  The launch lock above only orders the launches of one process; a second process on the same GPU
@@ -51,8 +69,10 @@ static void device_locks_init(void) { for (int i = 0; i < H264E_MAX_DEVICES; i++
  * last pool on that device is gone; a second process fails fast with a message that says who holds the device.
  * H264E_SHARE_DEVICE=1 skips the guard (e.g. to run two small encoders side by side on purpose).
  */
+#include <errno.h>
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/stat.h>
 #include <unistd.h>
 static pthread_mutex_t g_guard_mu = PTHREAD_MUTEX_INITIALIZER;
 static int g_guard_fd[H264E_MAX_DEVICES], g_guard_pools[H264E_MAX_DEVICES], g_guard_init;
@@ -69,7 +89,12 @@ static int process_guard_acquire(int device)
         if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess || !bus[0]) snprintf(bus, sizeof(bus), "dev%d", device);
         for (char *q = bus; *q; q++) if (*q == ':' || *q == '.' || *q == '/') *q = '_';
         snprintf(path, sizeof(path), "%s/h264e_mi355x_%s.lock", getenv("H264E_LOCK_DIR") ? getenv("H264E_LOCK_DIR") : "/tmp", bus);
-        const int fd = open(path, O_RDWR | O_CREAT, 0666);
+        /* O_CLOEXEC: the lock must not leak into fork+exec children (the device would stay "in use" while an unrelated child lives);
+         * O_NOFOLLOW: a planted symlink is refused, not followed and truncated; the file is made world-usable so that another user's
+         * encoder can take the same lock -- and when it still cannot be opened for that reason, somebody else's encoder owns it */
+        int fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC | O_NOFOLLOW, 0666);
+        if (fd >= 0) (void)fchmod(fd, 0666);
+        if (fd < 0 && (errno == EACCES || errno == EPERM)) fd = open(path, O_RDONLY | O_CLOEXEC | O_NOFOLLOW);      /* flock needs no write access */
         if (fd >= 0)
         {
             if (flock(fd, LOCK_EX | LOCK_NB))
@@ -86,10 +111,20 @@ static int process_guard_acquire(int device)
             {
                 char me[32];
                 const int n = snprintf(me, sizeof(me), "%ld\n", (long)getpid());
-                if (ftruncate(fd, 0) == 0 && write(fd, me, (size_t)n) != n) { /* the pid is informational */ }
+                if (ftruncate(fd, 0) == 0 && write(fd, me, (size_t)n) != n) { /* the pid is informational (and not writable through a read-only descriptor) */ }
                 g_guard_fd[device] = fd;
             }
-        }       /* (no lock directory: no guard) */
+        } else if (errno == EACCES || errno == EPERM)
+        {
+            snprintf(g_err, sizeof(g_err), "device %d: lock file %.100s belongs to another user (their encoder owns the device); H264E_SHARE_DEVICE=1 overrides", device, path);
+            g_guard_pools[device]--;
+            rc = -1;
+        } else if (errno != ENOENT && errno != ENOTDIR)
+        {
+            snprintf(g_err, sizeof(g_err), "device %d: cannot open lock file %.100s: %.40s (see H264E_LOCK_DIR, H264E_SHARE_DEVICE)", device, path, strerror(errno));
+            g_guard_pools[device]--;
+            rc = -1;
+        }       /* (no lock directory at all: no guard) */
     }
     pthread_mutex_unlock(&g_guard_mu);
     return rc;
@@ -116,6 +151,7 @@ struct h264e_hip_pool
     h264e_frame_task_t *tasks_dev;       /* ring of TASK_RING task arrays */
     int *progress_all;
     int *errflag;
+    unsigned long long *mb_counter;      /* device: macroblocks reconstructed by this pool's rows, delivered or not (h264e_hip_mb_counter) */
     uint32_t *order;                     /* device [nchains*(nmby+1)] (job << 16) | row in dispatch order of the current launch shape */
     uint32_t *order_host;                /* host copy being built (build_order) */
     int order_jobs, order_narrow;        /* the launch shape `order` holds: jobs, window geometry (-1: none yet) */
@@ -166,9 +202,13 @@ struct h264e_hip_group
     pthread_mutex_t mu;
     pthread_cond_t cv;
     hipStream_t stream;
-    hipEvent_t ev_done, ev_t0, ev_t1;
+    hipEvent_t ev_done, ev_t0[2], ev_t1[2];     /* launch times per window geometry (a round has at most one launch of each) */
+    int timed[2];                        /* which of the two launched in the last round */
     h264e_frame_task_t *tasks_dev; size_t tasks_cap;
     uint32_t *order_dev; size_t order_cap;
+    int holds_device;                    /* the group's merged launch owns the device's launch token (taken at the launch, given back when it has drained) */
+    int last_variant[2];                 /* kernel variant of the last round's launches, per window geometry (-1: none): for tests and logs */
+    char err[256];                       /* why the last round failed: every member reports it, not only the thread that launched */
 };
 
 extern "C" int h264e_hip_device_count(void)
@@ -181,15 +221,14 @@ extern "C" int h264e_hip_device_count(void)
 static void device_acquire(h264e_hip_pool_t *p)
 {
     if (p->holds_device) return;
-    pthread_once(&g_device_lock_once, device_locks_init);
-    pthread_mutex_lock(&g_device_lock[(unsigned)p->device % H264E_MAX_DEVICES]);
+    device_token_take(p->device);
     p->holds_device = 1;
 }
 static void device_release(h264e_hip_pool_t *p)
 {
     if (!p->holds_device) return;
     p->holds_device = 0;
-    pthread_mutex_unlock(&g_device_lock[(unsigned)p->device % H264E_MAX_DEVICES]);
+    device_token_give(p->device);
 }
 
 extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
@@ -351,6 +390,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         p->tasks_dev = (h264e_frame_task_t *)carve(sizeof(h264e_frame_task_t)*(size_t)nchains*TASK_RING, 256);
         p->progress_all = (int *)carve(sizeof(int)*2*(size_t)nchains*G.nmby, 256);     /* per slot: nmby row counters, then nmby `decided` counters */
         p->errflag = (int *)carve(sizeof(int), 256);
+        p->mb_counter = (unsigned long long *)carve(sizeof(unsigned long long), 256);
         p->stepflags = (int *)carve(sizeof(int)*2*(size_t)nchains, 256);
         p->abort_dev = (int *)carve(64, 256);
         p->walkrec = (h264e_walkrec_t *)carve(sizeof(h264e_walkrec_t)*(size_t)nchains, 256);
@@ -518,13 +558,19 @@ extern "C" int h264e_hip_sync(h264e_hip_pool_t *p)
     if (p->group)
     {
         /* the merged launch of the round this pool submitted in (all members' jobs) */
-        const hipError_t eg = hipEventSynchronize(p->group->ev_done);
+        h264e_hip_group_t *g = p->group;
+        const hipError_t eg = hipEventSynchronize(g->ev_done);
+        /* the merged launch has drained (or is lost): the first member to see that gives the device's launch token back */
+        pthread_mutex_lock(&g->mu);
+        if (g->holds_device && !g->arrived) { g->holds_device = 0; device_token_give(g->device); }
+        pthread_mutex_unlock(&g->mu);
         if (eg != hipSuccess) FAIL("group launch: %s", hipGetErrorString(eg));
-        if (p->profile && p->group->nmembers && p->group->member[0] == p)
-        {
-            float a = 0;
-            if (hipEventElapsedTime(&a, p->group->ev_t0, p->group->ev_t1) == hipSuccess) { p->prof_mb_ms += a; p->prof_launches++; }
-        }
+        if (p->profile && g->nmembers && g->member[0] == p)
+            for (int k = 0; k < 2; k++)
+            {
+                float a = 0;
+                if (g->timed[k] && hipEventElapsedTime(&a, g->ev_t0[k], g->ev_t1[k]) == hipSuccess) { p->prof_mb_ms += a; p->prof_launches++; }
+            }
     }
     {
         const hipError_t es = hipStreamSynchronize(p->stream);
@@ -580,43 +626,76 @@ extern "C" int h264e_hip_group_create(h264e_hip_group_t **out, int device)
     g->device = device;
     pthread_mutex_init(&g->mu, 0); pthread_cond_init(&g->cv, 0);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&g->stream) != hipSuccess) { free(g); FAIL("group_create: no stream on device %d", device); }
-    (void)hipEventCreate(&g->ev_done); (void)hipEventCreate(&g->ev_t0); (void)hipEventCreate(&g->ev_t1);
+    (void)hipEventCreate(&g->ev_done);
+    for (int k = 0; k < 2; k++) { (void)hipEventCreate(&g->ev_t0[k]); (void)hipEventCreate(&g->ev_t1[k]); g->last_variant[k] = -1; }
     *out = g;
     return 0;
 }
 
-/* all members that are still in the group have submitted: merge and launch (g->mu held).  Members whose launches differ in kernel
- * variant (window geometry, waves per row) go in separate launches, one after the other. */
+/* Kernel variant of a launch that offers `rows` macroblock rows in `wgs` workgroups (bk_launch_mb): 0 intra frames only; 4 two waves per
+ * row at 4 per SIMD (2048 resident workgroups) where the rows fill the chip; 3 the four-wave latency variant (192 VGPRs: 512 resident
+ * workgroups) ONLY where the whole grid is resident anyway -- its far reads may wait for any workgroup of the grid; 2 in between. */
+#define H264E_RESIDENT_WG_V2 1536
+#define H264E_RESIDENT_WG_V3 512
+static int pick_variant(int forced, int all_intra, int rows, int wgs)
+{
+    if (forced) return forced;
+    if (all_intra) return 0;
+    if (rows >= H264E_RESIDENT_WG_V2) return 4;
+    if (wgs <= H264E_RESIDENT_WG_V3) return 3;
+    return 2;
+}
+
+/* all members that are still in the group have submitted: merge and launch (g->mu held).  ONE launch per window geometry (narrow /
+ * wide: different kernels), its variant chosen from the MERGED grid: a member's own few rows say nothing about how full the chip will
+ * be, and the four-wave latency variant (512 resident workgroups) must never carry a grid that does not fit the chip. */
 static int group_launch_locked(h264e_hip_group_t *g)
 {
     int rc = 0;
-    if (hipSetDevice(g->device) != hipSuccess) rc = -1;
-    for (int variant = 0; variant < 10 && !rc; variant++)
+    size_t need_tasks = 0, need_order = 0, task_off = 0, order_off = 0;
+    g->err[0] = 0;
+    g->timed[0] = g->timed[1] = 0;
+    g->last_variant[0] = g->last_variant[1] = -1;
+#define GFAIL(...) do { snprintf(g->err, sizeof(g->err), __VA_ARGS__); rc = -1; } while (0)
+    if (hipSetDevice(g->device) != hipSuccess) GFAIL("group launch: hipSetDevice(%d) failed", g->device);
+    /* buffers for the whole round, sized BEFORE the first launch: growing them between two launches of a round would free memory the first
+     * one is still reading */
+    for (int k = 0; k < g->nmembers; k++)
+        if (g->pend[k]) { need_tasks += (size_t)g->pend_jobs[k]; need_order += (size_t)g->pend_jobs[k]*(size_t)(g->member[k]->G.nmby + 1); }
+    if (!rc && need_tasks > g->tasks_cap)
     {
-        const int narrow = variant & 1, waves = variant >> 1;
-        int idx[H264E_GROUP_MAX], n = 0, jobs = 0;
+        if (g->tasks_dev) (void)hipFree(g->tasks_dev);           /* (synchronises with the previous round's launch, which every member has waited for anyway) */
+        g->tasks_cap = need_tasks + 64;
+        if (hipMalloc((void **)&g->tasks_dev, sizeof(h264e_frame_task_t)*g->tasks_cap) != hipSuccess) { g->tasks_dev = 0; g->tasks_cap = 0; GFAIL("group launch: device allocation failed"); }
+    }
+    if (!rc && need_order > g->order_cap)
+    {
+        if (g->order_dev) (void)hipFree(g->order_dev);
+        g->order_cap = need_order + 4096;
+        if (hipMalloc((void **)&g->order_dev, sizeof(uint32_t)*g->order_cap) != hipSuccess) { g->order_dev = 0; g->order_cap = 0; GFAIL("group launch: device allocation failed"); }
+    }
+    /* the merged launch owns the device like any other persistent launch (g_device_held): taken here, given back by the first member whose
+     * h264e_hip_sync sees the launch drained, or when the group goes away */
+    if (!rc && need_tasks && !g->holds_device) { device_token_take(g->device); g->holds_device = 1; }
+    for (int narrow = 0; narrow < 2 && !rc; narrow++)
+    {
+        int idx[H264E_GROUP_MAX], n = 0, jobs = 0, forced = 0, all_intra = 1;
         for (int k = 0; k < g->nmembers; k++)
-            if (g->pend[k] && g->pend_narrow[k] == narrow && g->pend_waves[k] == waves) { idx[n++] = k; jobs += g->pend_jobs[k]; }
+            if (g->pend[k] && g->pend_narrow[k] == narrow)
+            {
+                idx[n++] = k; jobs += g->pend_jobs[k];
+                if (g->pend_waves[k] > 0) forced = g->pend_waves[k];     /* H264E_WAVES: the same for every pool of the process */
+                if (g->pend_waves[k] != 0) all_intra = 0;               /* 0 = a launch of intra frames only, -1 = to be chosen here */
+            }
         if (!n) continue;
         const h264e_geom_t &G = g->member[idx[0]]->G;
         const int rows = G.nmby + 1, lag = narrow ? H264E_NARROW_FRAME_LAG : H264E_FRAME_LAG;
         const size_t total = (size_t)jobs*rows;
-        if (jobs >= 65536) { snprintf(g_err, sizeof(g_err), "group launch: too many jobs"); rc = -1; break; }
-        if ((size_t)jobs > g->tasks_cap)
-        {
-            if (g->tasks_dev) (void)hipFree(g->tasks_dev);
-            g->tasks_cap = (size_t)jobs + 64;
-            if (hipMalloc((void **)&g->tasks_dev, sizeof(h264e_frame_task_t)*g->tasks_cap) != hipSuccess) { g->tasks_dev = 0; g->tasks_cap = 0; snprintf(g_err, sizeof(g_err), "group launch: device allocation failed"); rc = -1; break; }
-        }
-        if (total > g->order_cap)
-        {
-            if (g->order_dev) (void)hipFree(g->order_dev);
-            g->order_cap = total + 4096;
-            if (hipMalloc((void **)&g->order_dev, sizeof(uint32_t)*g->order_cap) != hipSuccess) { g->order_dev = 0; g->order_cap = 0; snprintf(g_err, sizeof(g_err), "group launch: device allocation failed"); rc = -1; break; }
-        }
+        const int variant = pick_variant(forced, all_intra, jobs*G.nmby, (int)total);
+        if (jobs >= 65536) { GFAIL("group launch: too many jobs"); break; }
         h264e_frame_task_t *th = (h264e_frame_task_t *)malloc(sizeof(h264e_frame_task_t)*(size_t)jobs);
         uint32_t *oh = (uint32_t *)malloc(sizeof(uint32_t)*total);
-        if (!th || !oh) { free(th); free(oh); snprintf(g_err, sizeof(g_err), "out of host memory"); rc = -1; break; }
+        if (!th || !oh) { free(th); free(oh); GFAIL("out of host memory"); break; }
         /* jobs member after member; dispatch order by start step lag*job + 2*row (a counting sort over all members: ties go member by
          * member, so the streams are interleaved frame by frame) */
         int base[H264E_GROUP_MAX], maxjobs = 0;
@@ -629,7 +708,7 @@ static int group_launch_locked(h264e_hip_group_t *g)
         }
         const int maxkey = lag*(maxjobs - 1) + 2*(rows - 1);
         int *start = (int *)calloc((size_t)maxkey + 2, sizeof(int));
-        if (!start) { free(th); free(oh); snprintf(g_err, sizeof(g_err), "out of host memory"); rc = -1; break; }
+        if (!start) { free(th); free(oh); GFAIL("out of host memory"); break; }
         for (int i = 0; i < n; i++) for (int j = 0; j < g->pend_jobs[idx[i]]; j++) for (int r = 0; r < rows; r++) start[lag*j + 2*r + 1]++;
         for (int k = 0; k <= maxkey; k++) start[k + 1] += start[k];
         for (int j = 0; j < maxjobs; j++)
@@ -641,21 +720,28 @@ static int group_launch_locked(h264e_hip_group_t *g)
         for (int i = 0; i < n && !rc; i++)
         {
             h264e_hip_pool_t *p = g->member[idx[i]];
-            if (hipEventRecord(p->ev_prep, p->stream) != hipSuccess || hipStreamWaitEvent(g->stream, p->ev_prep, 0) != hipSuccess) rc = -1;
+            if (hipEventRecord(p->ev_prep, p->stream) != hipSuccess || hipStreamWaitEvent(g->stream, p->ev_prep, 0) != hipSuccess) GFAIL("group launch: cannot order the launch behind a member's stream");
         }
-        if (!rc && (hipMemcpyAsync(g->tasks_dev, th, sizeof(h264e_frame_task_t)*(size_t)jobs, hipMemcpyHostToDevice, g->stream) != hipSuccess ||
-                    hipMemcpyAsync(g->order_dev, oh, sizeof(uint32_t)*total, hipMemcpyHostToDevice, g->stream) != hipSuccess)) rc = -1;
+        h264e_frame_task_t *td = g->tasks_dev + task_off;
+        uint32_t *od = g->order_dev + order_off;
+        if (!rc && (hipMemcpyAsync(td, th, sizeof(h264e_frame_task_t)*(size_t)jobs, hipMemcpyHostToDevice, g->stream) != hipSuccess ||
+                    hipMemcpyAsync(od, oh, sizeof(uint32_t)*total, hipMemcpyHostToDevice, g->stream) != hipSuccess)) GFAIL("group launch: task upload failed");
         free(th); free(oh);            /* pageable sources: staged before the calls return */
         if (!rc)
         {
-            (void)hipEventRecord(g->ev_t0, g->stream);
-            bk_launch_mb(G, narrow, waves, (unsigned)total, g->tasks_dev, g->order_dev, g->stream);
-            (void)hipEventRecord(g->ev_t1, g->stream);
-            if (hipGetLastError() != hipSuccess) rc = -1;
+            (void)hipEventRecord(g->ev_t0[narrow], g->stream);
+            bk_launch_mb(G, narrow, variant, (unsigned)total, td, od, g->stream);
+            (void)hipEventRecord(g->ev_t1[narrow], g->stream);
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) GFAIL("group launch: %s", hipGetErrorString(le));
+            else { g->timed[narrow] = 1; g->last_variant[narrow] = variant; }
         }
-        if (rc && !g_err[0]) snprintf(g_err, sizeof(g_err), "group launch failed");
+        task_off += (size_t)jobs; order_off += total;
     }
-    if (hipEventRecord(g->ev_done, g->stream) != hipSuccess) rc = -1;
+#undef GFAIL
+    if (hipEventRecord(g->ev_done, g->stream) != hipSuccess && !rc) { snprintf(g->err, sizeof(g->err), "group launch: hipEventRecord failed"); rc = -1; }
+    if (rc && !g->err[0]) snprintf(g->err, sizeof(g->err), "group launch failed");
+    if (rc) snprintf(g_err, sizeof(g_err), "%s", g->err);
     for (int k = 0; k < g->nmembers; k++) { free(g->pend_tasks[k]); g->pend_tasks[k] = 0; g->pend[k] = 0; }
     g->arrived = 0;
     g->failed = rc;
@@ -685,8 +771,8 @@ static int group_submit(h264e_hip_pool_t *p, const h264e_frame_task_t *host, int
         while (g->round == r) pthread_cond_wait(&g->cv, &g->mu);
         rc = g->failed;
     }
+    if (rc) snprintf(g_err, sizeof(g_err), "%s", g->err[0] ? g->err : "group launch failed");       /* g_err is per thread: every member gets the text */
     pthread_mutex_unlock(&g->mu);
-    if (rc && !g_err[0]) snprintf(g_err, sizeof(g_err), "group launch failed");
     return rc;
 }
 
@@ -696,7 +782,8 @@ extern "C" int h264e_hip_group_join(h264e_hip_group_t *g, h264e_hip_pool_t *p)
     pthread_mutex_lock(&g->mu);
     /* how many streams one grid can hold: a far reference read waits for a workgroup up to (12 - lag) dispatch keys AHEAD of its own
      * (enc_kernels.h rv_wait_rect), i.e. about (12 - lag)*(nmby + 1)/2 workgroups per member stream, and all of those must be resident
-     * together with the waiting one -- out of the ~1536 two-wave workgroups the chip holds at 3 waves per SIMD, with a margin */
+     * together with the waiting one.  The variant is chosen from the merged grid (pick_variant): the two-wave kernels hold 1536 / 2048
+     * workgroups -- 1400 with a margin --, and the four-wave latency variant (512) only ever carries a grid that is resident as a whole */
     const int window = (12 - H264E_NARROW_FRAME_LAG)*(p->G.nmby + 1)/2, room = 1400/(window > 0 ? window : 1);
     int bad = g->nmembers >= H264E_GROUP_MAX || (g->nmembers >= 1 && g->nmembers >= room) || p->device != g->device || g->arrived;
     if (!bad && g->nmembers)
@@ -728,6 +815,13 @@ extern "C" void h264e_hip_group_leave(h264e_hip_group_t *g, h264e_hip_pool_t *p)
         g->pend_tasks[g->nmembers] = 0; g->pend[g->nmembers] = 0;
         /* the others may have been waiting for this member only */
         if (g->nmembers && g->arrived == g->nmembers) (void)group_launch_locked(g);
+        if (!g->nmembers && g->holds_device)
+        {
+            /* the last member is gone: nobody will sync the group's launches any more */
+            (void)hipSetDevice(g->device);
+            (void)hipStreamSynchronize(g->stream);
+            g->holds_device = 0; device_token_give(g->device);
+        }
     }
     p->group = 0;
     pthread_mutex_unlock(&g->mu);
@@ -741,7 +835,9 @@ extern "C" void h264e_hip_group_destroy(h264e_hip_group_t *g)
     for (int k = 0; k < g->nmembers; k++) { g->member[k]->group = 0; free(g->pend_tasks[k]); }
     if (g->tasks_dev) (void)hipFree(g->tasks_dev);
     if (g->order_dev) (void)hipFree(g->order_dev);
-    (void)hipEventDestroy(g->ev_done); (void)hipEventDestroy(g->ev_t0); (void)hipEventDestroy(g->ev_t1);
+    if (g->holds_device) { g->holds_device = 0; device_token_give(g->device); }
+    (void)hipEventDestroy(g->ev_done);
+    for (int k = 0; k < 2; k++) { (void)hipEventDestroy(g->ev_t0[k]); (void)hipEventDestroy(g->ev_t1[k]); }
     (void)hipStreamDestroy(g->stream);
     pthread_mutex_destroy(&g->mu); pthread_cond_destroy(&g->cv);
     free(g);
@@ -835,6 +931,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         }
         d.chain_desc = p->chains_dev + d.chain;
         d.errflag = p->errflag;
+        d.mb_counter = p->mb_counter;
         d.stepflags = p->stepflags + 2*c;
         d.frame_slot = t.frame_slot;
         d.first_row = (t.stream_mode && t.first_row > 0 && t.first_row < G.nmby) ? t.first_row : 0;
@@ -870,7 +967,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         if (d.walk_on_device) p->traj_cur[t.slot] ^= 1;         /* this launch's walk writes the other buffer: it is the latest from now on */
     }
     if (!any) { free(host); return 0; }
-    if (!p->group) device_acquire(p);   /* one launch at a time per device (see g_device_lock); a launch group owns the device as a whole (h264e_hip_group_join) */
+    if (!p->group) device_acquire(p);   /* one launch at a time per device (see g_device_held); a launch group takes the token for its merged launch (group_launch_locked) */
     if (any_narrow && any_wide) { free(host); FAIL("submit: the jobs of one launch must agree on narrow_window"); }
     h264e_frame_task_t *slot = p->tasks_dev + (size_t)p->ring_pos*p->nchains;
     p->ring_pos = (p->ring_pos + 1) % TASK_RING;
@@ -903,12 +1000,13 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
      * (rate control, the frame-at-a-time API) are pure latency and keep the 3-per-SIMD kernel with its fewer spills (10.5 vs 10.9 ms) */
     /* (... and 3 the latency variant -- four waves per row: the 8x8 partition search and the deblocking + stores on waves of their own:
      * launches of one or a few frames, where the chip is empty and only the macroblock latency counts: the frame-at-a-time API) */
-    const int waves = p->waves ? p->waves : all_intra ? 0 : (njobs*G.nmby >= 1536) ? 4 : (njobs*G.nmby <= 512) ? 3 : 2;
+    const int waves = pick_variant(p->waves, all_intra, njobs*G.nmby, njobs*(G.nmby + 1));
     (void)max_slices;
     if (p->group)
     {
-        /* member of a launch group: the launch is merged with the other members' (group_launch_locked) */
-        const int grc = group_submit(p, host, njobs, any_narrow, waves);
+        /* member of a launch group: the launch is merged with the other members' and the variant is chosen from the MERGED grid
+         * (group_launch_locked): this member only says what it cannot decide there -- forced by H264E_WAVES, intra frames only (0), or open (-1) */
+        const int grc = group_submit(p, host, njobs, any_narrow, p->waves ? p->waves : all_intra ? 0 : -1);
         free(host);
         return grc;
     }
@@ -1187,6 +1285,17 @@ extern "C" int h264e_hip_stamps_read(h264e_hip_pool_t *p, unsigned long long *ds
         if (reset) HIPCHK(hipMemset(p->chains_host[c].prof, 0, sizeof(t)));
         for (int i = 0; i < 32; i++) dst[i] += t[i];
     }
+    return 0;
+}
+
+/* macroblocks this pool's rows have reconstructed since the last reset -- everything the kernel worked on, including frames that a
+ * mis-speculation or a rate-control miss threw away.  Call after h264e_hip_sync. */
+extern "C" int h264e_hip_mb_counter(h264e_hip_pool_t *p, unsigned long long *count, int reset)
+{
+    if (!p || !count) FAIL("mb_counter: bad argument");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipMemcpy(count, p->mb_counter, sizeof(*count), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(hipMemset(p->mb_counter, 0, sizeof(*count)));
     return 0;
 }
 

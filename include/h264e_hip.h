@@ -160,6 +160,8 @@ int  h264e_hip_reset_results(h264e_hip_pool_t *pool, int chain);
  * arena space back, so the frame can be submitted again (re-encode path) */
 int  h264e_hip_rewind_frame(h264e_hip_pool_t *pool, int chain, int slot);
 /* kernel timing on the pool's stream (HIP events around every macroblock-kernel launch) */
+/* macroblocks the pool's rows have reconstructed since the last reset, delivered or thrown away (call after h264e_hip_sync) */
+int h264e_hip_mb_counter(h264e_hip_pool_t *pool, unsigned long long *count, int reset);
 void h264e_hip_profile(h264e_hip_pool_t *pool, int enable);
 int  h264e_hip_profile_read(h264e_hip_pool_t *pool, double *mb_kernel_ms, double *splice_kernel_ms, int *launches);
 /* diagnostic: per-phase cycle sums of a -DH264E_STAMPS build of the kernels (all zero in the product build) */

@@ -50,6 +50,8 @@ void h264o_close(h264o_enc_t *e);
 /* Encode the next frame.  *out points into encoder-owned memory, valid until the next call. */
 int  h264o_encode(h264o_enc_t *e, const uint8_t *const yuv[3], const int stride[3], uint8_t **out, int *out_bytes);
 int  h264o_get_qp(const h264o_enc_t *e);        /* QP of the last encoded frame */
+/* H:6898-6913 H264E_set_vbv_state (vbv_fullness_bytes < 0: no change) */
+void h264o_set_vbv_state(h264o_enc_t *e, int vbv_size_bytes, int vbv_fullness_bytes);
 void h264o_get_chain(const h264o_enc_t *e, h264o_chain_t *c);
 void h264o_set_chain(h264o_enc_t *e, const h264o_chain_t *c);
 /* copy of the last reconstructed (deblocked) frame, I420 w x h of the CODED size; returns coded w/h */

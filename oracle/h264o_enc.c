@@ -1152,6 +1152,17 @@ void h264o_set_chain(h264o_enc_t *e, const h264o_chain_t *c)
     e->clusters[0] = c->mv_clusters[0]; e->clusters[1] = c->mv_clusters[1]; e->next_idr_pic_id = c->next_idr_pic_id & 1;
 }
 
+/* H:6898-6913 H264E_set_vbv_state: new VBV size (SPS level at the next key frame, the controller's limits) and, when >= 0, fullness */
+void h264o_set_vbv_state(h264o_enc_t *e, int vbv_size_bytes, int vbv_fullness_bytes)
+{
+    e->par.vbv_size_bytes = vbv_size_bytes;
+    if (vbv_fullness_bytes >= 0)
+    {
+        e->rc.vbv_bits = vbv_fullness_bytes*8;
+        e->rc.vbv_target_level = e->rc.vbv_bits;
+    }
+}
+
 const h264o_mbtrace_t *h264o_get_trace(const h264o_enc_t *e, int *nmb) { if (nmb) *nmb = e->nmb; return e->trace; }
 
 void h264o_get_recon(const h264o_enc_t *e, uint8_t *dst, int *cw, int *ch)
@@ -1185,6 +1196,21 @@ int h264o_encode(h264o_enc_t *e, const uint8_t *const yuv[3], const int stride[3
     e->slice_type = key ? SLICE_I : SLICE_P;
     rc_frame_start(e, key);
 
+    if (e->par.vbv_size_bytes && e->rc.vbv_bits - e->desired_frame_bytes*8 > e->par.vbv_size_bytes*8)
+    {
+        /* H:6497-6510 "encode transparent frame on VBV overflow" (reachable only right after H264E_set_vbv_state: rc_frame_end clamps
+         * the fullness to the VBV size): slice header, one skip run over the whole picture -- written for key frames too --, and the
+         * reference picture as the reconstruction */
+        e->slice_start_row = e->slice_start_num = 0;
+        write_slice_header(e, key);
+        e->skip_run = e->nmb;
+        bw_ue(&e->bw, (uint32_t)e->skip_run);
+        nal_finish(e);
+        for (c = 0; c < 3; c++)
+            for (y = 0; y < (e->nmby*16 >> (c ? 1 : 0)); y++)
+                memcpy(e->dec[c] + (size_t)y*e->stride[c], e->ref[c] + (size_t)y*e->stride[c], (size_t)(e->nmbx*16 >> (c ? 1 : 0)));
+        rc_frame_end(e, key, 1);
+    } else
     {
         /* one slice, or N row bands (H:6511-6574): every band is a slice of its own -- contexts, availability, skip run and
          * the mv_clusters state restart at its first macroblock (the reference encodes each band with a COPY of the encoder and
@@ -1212,9 +1238,9 @@ int h264o_encode(h264o_enc_t *e, const uint8_t *const yuv[3], const int stride[3
             row0 = row1;
         }
         e->slice_start_row = e->slice_start_num = 0;
+        rc_frame_end(e, key, e->par.slices > 1 ? 0 : e->skip_run == e->nmb);       /* the parent's skip_run stays 0 in the threads build (H:6596) */
     }
 
-    rc_frame_end(e, key, e->par.slices > 1 ? 0 : e->skip_run == e->nmb);       /* the parent's skip_run stays 0 in the threads build (H:6596) */
     for (c = 0; c < 3; c++)
     {
         uint8_t *t = e->ref[c]; e->ref[c] = e->dec[c]; e->dec[c] = t;      /* H:3580-3596 */

@@ -50,10 +50,13 @@ CASES = {
     "4k_240_thr8": (3840, 2160, 240, "--qp 26 --gop 30 --threads 8", REF_THR),
     "8k_35": (7680, 4320, 35, "--qp 26 --gop 30", REF),                        # crosses a GOP boundary at 8K
     "8k_30_thr2_kbps": (7680, 4320, 30, "--kbps 60000 --gop 30 --threads 2", REF_THR),    # configs[4] over a full GOP
+    # BASELINE configs[3] at its stated length (round-3 VERDICT, missing item 2): 40 GOPs, ~15 min of the reference on one core
+    "4k_1200": (3840, 2160, 1200, "--qp 26 --gop 30", REF),
+    "4k_1200_thr8": (3840, 2160, 1200, "--qp 26 --gop 30 --threads 8", REF_THR),
 }
 
 
-def run_case(name, tmp):
+def run_case(name, tmp, keep_yuv=False):
     w, h, n, flags, binary = CASES[name][:5]
     clip = CASES[name][5] if len(CASES[name]) > 5 else "synth"
     yuv = os.path.join(tmp, "%s_%d_%dx%d.yuv" % (clip, n, w, h))
@@ -75,7 +78,8 @@ def run_case(name, tmp):
     with open(yuv, "rb") as f:
         for blk in iter(lambda: f.read(1 << 24), b""):
             h5.update(blk)
-    os.remove(yuv)
+    if not keep_yuv:
+        os.remove(yuv)
     e = dict(clip=clip, w=w, h=h, frames=n, flags=flags, input_md5=h5.hexdigest(), bytes=len(data),
              md5=hashlib.md5(data).hexdigest(), frame_bytes=sizes, ref_seconds=round(dt, 1),
              binary=os.path.basename(binary))
@@ -87,8 +91,10 @@ def main():
     names = sys.argv[1:] or list(CASES)
     have = json.load(open(OUT)) if os.path.exists(OUT) else {}
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-        for name in names:
-            have[name] = run_case(name, tmp)
+        for i, name in enumerate(names):
+            nxt = CASES[names[i + 1]] if i + 1 < len(names) else None
+            same = nxt is not None and nxt[:3] == CASES[name][:3] and (nxt[5:] == CASES[name][5:])     # the next case reads the same clip: keep the file
+            have[name] = run_case(name, tmp, keep_yuv=same)
             json.dump(have, open(OUT, "w"), indent=1, sort_keys=True)
 
 

@@ -35,6 +35,8 @@ def lib():
         _lib.h264o_encode.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         _lib.h264o_encode_clip.restype = C.c_long
         _lib.h264o_encode_clip.argtypes = [C.POINTER(Param), C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+        _lib.h264o_set_vbv_state.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        _lib.h264o_set_vbv_state.restype = None
         _lib.h264o_get_chain.argtypes = [C.c_void_p, C.POINTER(Chain)]
         _lib.h264o_set_chain.argtypes = [C.c_void_p, C.POINTER(Chain)]
         _lib.h264o_get_recon.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -79,6 +81,9 @@ class Encoder:
         p, n = C.c_void_p(), C.c_int()
         lib().h264o_encode(self.e, yuv, st, C.byref(p), C.byref(n))
         return C.string_at(p, n.value)
+
+    def set_vbv_state(self, vbv_size_bytes, vbv_fullness_bytes):
+        lib().h264o_set_vbv_state(self.e, vbv_size_bytes, vbv_fullness_bytes)
 
     def recon(self):
         cw, ch = C.c_int(), C.c_int()

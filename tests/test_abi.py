@@ -37,6 +37,10 @@ def test_struct_layouts_match_reference_abi():
     assert ctypes.sizeof(P.CreateParam) == 56 and P.CreateParam.num_layers.offset == 48
     assert ctypes.sizeof(P.RunParam) == 48 and P.RunParam.nalu_callback.offset == 32
     assert ctypes.sizeof(P.IoYuv) == 40
+    # the extension structs: the ctypes mirror against what the library was compiled with
+    L = P.load()
+    assert L.H264E_struct_size(0) == ctypes.sizeof(P.ClipParam)
+    assert L.H264E_struct_size(1) == ctypes.sizeof(P.ClipStats)
 
 
 def test_sizeof_and_parameter_errors_without_gpu():

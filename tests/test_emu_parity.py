@@ -5,6 +5,7 @@ import json
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 import clips
@@ -253,6 +254,52 @@ def test_encode_multi_equals_separate_encodes():
         assert out == wbytes and sizes == wsizes
 
 
+def test_launch_group_next_to_a_plain_clip_encoder_takes_turns():
+    """the group's merged launch and a plain clip encoder on the same device share the device's launch token (h264e_pool.h
+    device_token_take / give: taken on the launching thread, given back on whichever member thread sees the launch drained): both finish,
+    every stream is the oracle's (the emulation runs the product's pool / group code; launches are synchronous there, so what this
+    exercises is the token protocol -- no deadlock, no double release -- not wave-slot starvation, which the GPU test covers)"""
+    import threading
+    P = pkg.load_pkg()
+    w, h = 176, 144
+    c = clips.make("pan", w, h, 8)
+    want, wsizes = oracle_lib.encode_clip(c, w, h, gop=4, qp=26)
+    grp = []
+    for k in range(3):
+        e = P.ClipEncoder(w, h, 8 - k, gop=4, qp=26, lib=pkg.EMU_LIB)
+        e.upload(c[: 8 - k])
+        grp.append(e)
+    solo = P.ClipEncoder(w, h, 8, gop=4, qp=26, lib=pkg.EMU_LIB)
+    solo.upload(c)
+    res, errs = {}, []
+
+    def run_group():
+        try:
+            res["group"] = P.ClipEncoder.encode_multi(grp)
+        except Exception as ex:  # noqa: BLE001 -- reported below
+            errs.append(repr(ex))
+
+    def run_solo():
+        try:
+            res["solo"] = [solo.encode() for _ in range(3)]
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+
+    th = [threading.Thread(target=run_group), threading.Thread(target=run_solo)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in th), "deadlock between the launch group and the plain encoder"
+    for e in grp + [solo]:
+        e.close()
+    assert not errs, errs
+    for k, (out, sizes, st) in enumerate(res["group"]):
+        assert sizes == wsizes[: 8 - k] and out == want[: sum(wsizes[: 8 - k])]
+    for out, sizes, st in res["solo"]:
+        assert out == want and sizes == wsizes
+
+
 def test_emulation_refuses_non_device_addresses_in_global_accessors():
     """the tripwire for the address-space lesson of round 2 (a pointer to a register copy cast to a global pointer: a GPU memory fault the
     emulation could not see): every global-memory accessor of the kernel sources (wave.h cload / cstore / gload / dep_poll / g_atomic_*)
@@ -262,3 +309,72 @@ def test_emulation_refuses_non_device_addresses_in_global_accessors():
             "L.emu_check_global.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_int]; L.emu_check_global(C.addressof(b), 4, b'probe.h', 7)") % pkg.EMU_LIB
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode != 0 and "probe.h:7" in r.stderr and "not device memory" in r.stderr
+
+
+def _strided_planes(frame, w, h, pads=(32, 16, 8), fill=0xAA):
+    """the packed I420 frame as three separately allocated planes with row strides w + 32, w/2 + 16, w/2 + 8 (H264E_io_yuv_t allows any
+    stride, h264-lab.h:231-237); the padding holds a marker"""
+    out = []
+    off = 0
+    for c, pad in enumerate(pads):
+        pw, ph = (w, h) if c == 0 else (w // 2, h // 2)
+        buf = np.full((ph, pw + pad), fill, np.uint8)
+        buf[:, :pw] = frame[off: off + pw * ph].reshape(ph, pw)
+        off += pw * ph
+        out.append(buf)
+    return out
+
+
+def _check_strided(P, lib=None):
+    """strided, separately allocated planes through H264E_encode, read-only and with write-back (const_input_flag = 0): the stream is the
+    oracle's, the written-back planes are the oracle's reconstruction, the padding is untouched"""
+    w, h, n = 176, 144, 4
+    c = clips.make("synth", w, h, n)
+    for const_input in (1, 0):
+        o = oracle_lib.Encoder(w, h, gop=30, qp=26)
+        e = P.Encoder(w, h, gop=30, qp=26, const_input=const_input, **({"lib": lib} if lib else {}))
+        for t in range(n):
+            planes = _strided_planes(c[t], w, h)
+            got = e.encode_planes(planes[0][:, :w], planes[1][:, : w // 2], planes[2][:, : w // 2])
+            assert got == o.encode(c[t])
+            rec, cw, ch = o.recon()
+            want = c[t] if const_input else rec
+            off = 0
+            for k, pl in enumerate(planes):
+                pw, ph = (w, h) if k == 0 else (w // 2, h // 2)
+                assert np.array_equal(pl[:, :pw].ravel(), want[off: off + pw * ph]), "plane %d, frame %d, const_input %d" % (k, t, const_input)
+                assert (pl[:, pw:] == 0xAA).all(), "padding of plane %d was written" % k
+                off += pw * ph
+        e.close()
+        o.close()
+
+
+def test_strided_and_separately_allocated_planes():
+    """the host half of the drop-in API (plane upload with strides, write-back with strides) on the CPU, through the emulation"""
+    _check_strided(pkg.load_pkg(), lib=pkg.EMU_LIB)
+
+
+VBV_GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vbv.json")))
+
+
+def _run_vbv_case(enc, g):
+    """frame-at-a-time encode under --kbps with H264E_set_vbv_state called where the fixture says (tests/golden/vbv.json: streams of the
+    reference itself through oracle/vbv_harness.c, which calls the reference's own function)"""
+    c = clips.make("synth", g["w"], g["h"], g["frames"])
+    parts = []
+    for t in range(g["frames"]):
+        for at, size, full in g["events"]:
+            if at == t:
+                enc.set_vbv_state(size, full)
+        parts.append(enc.encode(c[t]))
+    assert [len(p) for p in parts] == g["frame_bytes"]
+    assert hashlib.md5(b"".join(parts)).hexdigest() == g["md5"]
+
+
+@pytest.mark.parametrize("name", sorted(VBV_GOLDEN))
+def test_set_vbv_state_mid_stream_matches_reference(name):
+    """H264E_set_vbv_state through the product's host code (the kernels emulated): round-3 VERDICT weak item 1, never called by any test before"""
+    g = VBV_GOLDEN[name]
+    e = pkg.load_pkg().Encoder(g["w"], g["h"], gop=g["gop"], kbps=g["kbps"], lib=pkg.EMU_LIB)
+    _run_vbv_case(e, g)
+    e.close()

@@ -167,3 +167,25 @@ def test_cli_gpus_option_shards_one_stream(app, tmp_path):
     assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
     assert hashlib.md5(out.read_bytes()).hexdigest() == g["md5"]
     assert b"GOP-sharded over 3 clip encoders" in r.stderr
+
+
+REF_DROPIN = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "encode_app_ref_dropin")
+
+
+@pytest.mark.parametrize("g", [g for g in GOLDEN if (g["w"], g["h"]) == (352, 288)][:4], ids=lambda g: g["flags"].replace(" ", ""))
+def test_reference_cli_linked_against_the_dropin(app, tmp_path, g):
+    """the reference's OWN, unmodified minih264e_test.c, compiled against include/h264e_mi355x.h and linked with libh264e_mi355x.so in the
+    build container (`make -C oracle dropin`, tests/test_dropin_link.py): the application the boundary exists for runs on the MI355X and
+    writes the reference encoder's bytes and stdout lines (--psnr: its PSNR line is computed from the written-back reconstruction)"""
+    if not os.path.exists(REF_DROPIN):
+        pytest.skip("oracle/_ref/encode_app_ref_dropin not built (needs the reference sources: build container)")
+    c = clips.make(g["clip"], g["w"], g["h"], g["frames"])
+    yuv = tmp_path / ("clip_%dx%d.yuv" % (g["w"], g["h"]))
+    yuv.write_bytes(c.tobytes())
+    out = tmp_path / "o.264"
+    r = subprocess.run([REF_DROPIN, "--input", str(yuv), "--output", str(out)] + g["flags"].split() + ["--stats", "x"], capture_output=True, timeout=300, cwd=str(tmp_path))
+    text = r.stdout.decode()
+    assert r.returncode == 0, text + r.stderr.decode()
+    assert "sizeof_persist = 369840 sizeof_scratch = 239743" in text
+    assert ["frame=%d, bytes=%d" % (i, b) for i, b in enumerate(g["frame_bytes"])] == [l for l in text.splitlines() if l.startswith("frame=")]
+    assert hashlib.md5(out.read_bytes()).hexdigest() == g["md5"]

@@ -118,3 +118,29 @@ def test_oracle_row_bands_vs_compiled_reference(tmp_path, slices, flags):
     kw["slices"] = slices
     data, _ = oracle_lib.encode_clip(c, w, h, **kw)
     assert data == out.read_bytes()
+
+
+VBV_GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vbv.json")))
+
+
+def _run_vbv_case(enc, g):
+    """frame-at-a-time encode under --kbps with H264E_set_vbv_state called where the fixture says (tests/golden/vbv.json: streams of the
+    reference itself through oracle/vbv_harness.c, which calls the reference's own function)"""
+    c = clips.make("synth", g["w"], g["h"], g["frames"])
+    parts = []
+    for t in range(g["frames"]):
+        for at, size, full in g["events"]:
+            if at == t:
+                enc.set_vbv_state(size, full)
+        parts.append(enc.encode(c[t]))
+    assert [len(p) for p in parts] == g["frame_bytes"]
+    assert hashlib.md5(b"".join(parts)).hexdigest() == g["md5"]
+
+
+@pytest.mark.parametrize("name", sorted(VBV_GOLDEN))
+def test_oracle_set_vbv_state_matches_reference(name):
+    """the oracle's restatement of H264E_set_vbv_state (h264-lab.h:6898-6913) and of the transparent frame on VBV overflow (:6497-6510)"""
+    g = VBV_GOLDEN[name]
+    o = oracle_lib.Encoder(g["w"], g["h"], gop=g["gop"], kbps=g["kbps"])
+    _run_vbv_case(o, g)
+    o.close()
