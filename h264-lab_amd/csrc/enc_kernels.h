@@ -91,6 +91,18 @@ DEV void bw_put(BitW &b, int n, uint32_t v)
         b.acc &= (1ull << b.nacc) - 1;
     }
 }
+/* The writer's state lives in LDS between macroblocks; what comes back from LDS is a vector register as far as the compiler knows, and
+ * every bw_put on it would run on the vector unit (64-bit shifts, compares and branches through the exec mask -- measured: 1.2 k of
+ * the kernel's static vector instructions).  The state is wave-uniform: say so once per macroblock, and the writer runs on the scalar
+ * unit. */
+DEV BitW bw_uniform(const BitW &s)
+{
+    BitW b;
+    b.acc = (uint64_t)(uint32_t)uni((int)(uint32_t)s.acc) | ((uint64_t)(uint32_t)uni((int)(uint32_t)(s.acc >> 32)) << 32);
+    b.nacc = uni(s.nacc); b.pos = (uint32_t)uni((int)s.pos); b.cap = (uint32_t)uni((int)s.cap); b.overflow = uni(s.overflow);
+    b.buf = uniptr(s.buf);
+    return b;
+}
 DEV int ue_len(uint32_t v) { return 2*(32 - clz32(v + 1)) - 1; }                    /* H:3402 */
 DEV void bw_ue(BitW &b, uint32_t v)                                                 /* H:2738 */
 {
@@ -686,92 +698,72 @@ DEV void wave_pred_chroma(uint8_t *dst, const uint8_t *left, const uint8_t *top,
 }
 
 /*
- * One row (4 samples) of intra 4x4 prediction mode m (H.264 8.3.1.2; same samples as H:1834-1960).
- * edge (LDS) holds the 13 neighbours along the block border: edge[4 + i] = sample i steps clockwise from the
- * top-left corner (i = -4..-1 left column bottom-up, 0 corner, 1..8 top row incl. top-right).
- */
-DEV uint32_t i4_pred_row(int m, const uint8_t *edge, int dc, uint32_t lut01, uint32_t lut23 /* the row's four k_i4_lut entries, two per word */)
-{
-    if (m == 2) return (uint32_t)dc*0x01010101u;
-    uint32_t o = 0;
-#pragma unroll
-    for (int x = 0; x < 4; x++)
-    {
-        const uint32_t e = ((x < 2 ? lut01 : lut23) >> (16*(x & 1))) & 0xffffu;
-        const int t = (int)(e & 3), a = edge[(e >> 2) & 15], b = edge[(e >> 6) & 15], c = edge[(e >> 10) & 15];
-        const int v = t == 0 ? (a + 2*b + c + 2) >> 2 : t == 1 ? (a + b + 1) >> 1 : t == 2 ? a : (a + 3*b + 2) >> 2;
-        o |= (uint32_t)v << (8*x);
-    }
-    return o;
-}
-
-/*
- * H:1810-1962 h264e_intra_choose_4x4: all nine modes evaluated at once, lane = (mode slot, row), each lane
- * predicts its row and takes its SAD.  Test order DC,V,DDL,VL,H,HU,DDR,HD,VR with a strict "<" keeps the
- * reference's tie-breaks.  top8 / leftcol (stride lstride) / tl point into the LDS working picture.
+ * H:1810-1962 h264e_intra_choose_4x4: all nine modes evaluated at once, lane = (mode slot, row).
+ * Every predicted sample of every mode (H.264 8.3.1.2; same samples as H:1834-1960) is one of the 13 border samples E[k] (left column
+ * bottom-up, corner, top row incl. top-right), a 3-tap value F3[k] = (E[k-1] + 2 E[k] + E[k+1] + 2) >> 2 (border replicated at both
+ * ends: that IS the two (a + 3b + 2) >> 2 corner cases), a 2-tap value F2[k] = (E[k] + E[k+1] + 1) >> 1, or the DC.  So the block's 14
+ * border lanes build that pool once (their neighbours' samples come through DPP row shifts) and every (mode, row) lane only GATHERS its
+ * four samples by the offsets of tables.h k_i4_sel, takes its SAD, the four row SADs of a mode are added inside the quad, and the
+ * minimum over the modes -- cost << 4 | slot, so that the earliest slot wins ties exactly like the reference's strict "<" in its test
+ * order DC,V,DDL,VL,H,HU,DDR,HD,VR -- is two DPP row rotations and three lane reads.
+ * blk = the block's top-left sample in the LDS working picture (row stride bstride; row -1 / column -1 hold the neighbours);
  * in = input block (stride 16), pred = LDS output (stride 16); returns mode | cost << 4.
- * scratch (LDS): edge[16] bytes + the prediction lookup table; lut01 / lut23 (i4_lut_lanes): every lane's own four table entries,
- * which never change (lane = mode slot, row), fetched once per macroblock instead of once per sample.
  */
-struct I4Scratch { uint8_t edge[16]; uint16_t lut[9*16]; };
+struct I4Scratch { alignas(4) uint8_t pool[48]; };      /* E at 0..13, F3 at 16..28, F2 at 32..43, (DC at 47 in k_i4_sel: taken from a register) */
 
-/* lane 4k + y -> the table entries of mode slot k, row y: samples 0,1 (which = 0) or 2,3 (which = 1), 16 bits each */
-DEV V64 i4_lut_lanes(const I4Scratch &S, int which)
+DEV int i4_slot_mode(int k) { return k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 3 : k == 3 ? 7 : k == 4 ? 1 : k == 5 ? 8 : k == 6 ? 4 : k == 7 ? 6 : 5; }
+/* lane 4k + y -> the four pool offsets of mode slot k, row y; never change: fetched once per macroblock */
+DEV V64 i4_sel_lanes()
 {
-    return v64_make([&](int l) -> int {
-        const int k = l >> 2, y = l & 3;
-        if (k >= 9) return 0;
-        const int m = k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 3 : k == 3 ? 7 : k == 4 ? 1 : k == 5 ? 8 : k == 6 ? 4 : k == 7 ? 6 : 5;
-        return (int)((uint32_t)S.lut[16*m + 4*y + 2*which] | ((uint32_t)S.lut[16*m + 4*y + 2*which + 1] << 16));
-    });
+    return v64_make([&](int l) -> int { const int k = l >> 2; return k < 9 ? (int)k_i4_sel[i4_slot_mode(k)][l & 3] : 0; });
 }
-DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_t *top8, const uint8_t *leftcol, int lstride,
-                       int mpred, int penalty, I4Scratch &S, const V64 &lut01, const V64 &lut23)
+DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_t *blk, int bstride, int mpred, int penalty, I4Scratch &S, const V64 &sel)
 {
-    WAVE_FOR(l)
-    {
-        if (l < 4) S.edge[3 - l] = leftcol[l*lstride];
-        else if (l == 4) S.edge[4] = top8[-1];
-        else if (l < 13)
-        {
-            int k = l - 5;
-            S.edge[5 + k] = top8[(k > 3 && !(avail & AV_TR)) ? 3 : k];
-        }
-    }
-    wave_sync();
+    /* border samples E[0..13] in lanes 0..13 (E[13] = E[12]); without a top-right block its four samples repeat top[3] */
+    const V64 e = v64_make([&](int l) -> int {
+        if (l > 13) return 0;
+        const int k = l > 12 ? 12 : l;
+        if (k < 4) return (int)blk[(3 - k)*bstride - 1];
+        if (k == 4) return (int)blk[-bstride - 1];
+        const int t = k - 5;
+        return (int)blk[-bstride + ((t > 3 && !(avail & AV_TR)) ? 3 : t)];
+    });
+    const V64 em = v64_row_shr1(e), ep = v64_row_shl1(e);        /* E[k-1] (E[0] itself for k = 0), E[k+1] */
+    v64_each3(e, em, ep, [&](int l, int c, int a, int b) {
+        if (l < 13) { S.pool[l] = (uint8_t)c; S.pool[16 + l] = (uint8_t)((a + 2*c + b + 2) >> 2); S.pool[32 + l] = (uint8_t)((c + b + 1) >> 1); }
+    });
     int dc;
     {
-        const uint32_t lw = lds32(S.edge), tw = lds32u((const lu8 *)(S.edge + 5));
-        const int sl = (int)((lw & 255) + ((lw >> 8) & 255) + ((lw >> 16) & 255) + (lw >> 24));
-        const int st = (int)((tw & 255) + ((tw >> 8) & 255) + ((tw >> 16) & 255) + (tw >> 24));
+        /* H:1625-1651: lane k of s4 = E[k] + .. + E[k+3]: the left column's sum in lane 0, the top row's in lane 5 */
+        const V64 s2 = v64_map(ep, [&](int l, int b) -> int { return v64_own(e, l) + b; });
+        const V64 s4 = v64_map(v64_row_shl1(v64_row_shl1(s2)), [&](int l, int b) -> int { return v64_own(s2, l) + b; });
+        const int sl = v64_read(s4, 0), st = v64_read(s4, 5);
         const int hl = (avail & AV_L) != 0, ht = (avail & AV_T) != 0;
         dc = (hl && ht) ? (sl + st + 4) >> 3 : hl ? (sl + 2) >> 2 : ht ? (st + 2) >> 2 : 128;
     }
-    const int have_t = (avail & AV_T) != 0, have_l = (avail & AV_L) != 0, have_all = (avail & (AV_T | AV_L | AV_TL)) == (AV_T | AV_L | AV_TL);
-    int best = 0, best_sad = 0;
-    {
-        /* the rows and their SADs stay in registers (wave.h V64): lane 4k + y holds row y of mode slot k, the four row SADs of a slot
-         * are added inside the quad and read lane by lane -- no LDS round trips for the choice */
-        const V64 row = v64_map(lut01, [&](int l, int e01) -> int {
-            const int k = l >> 2;
-            if (k >= 9) return 0;
-            const int m = k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 3 : k == 3 ? 7 : k == 4 ? 1 : k == 5 ? 8 : k == 6 ? 4 : k == 7 ? 6 : 5;
-            return (int)i4_pred_row(m, S.edge, dc, (uint32_t)e01, (uint32_t)v64_own(lut23, l));
-        });
-        const V64 qs = v64_quad_sum(v64_map(row, [&](int l, int r) -> int { return (l >> 2) < 9 ? (int)sad4_u8(lds32(in + 16*(l & 3)), (uint32_t)r, 0) : 0; }));
-#pragma unroll
-        for (int kk = 0; kk < 9; kk++)
-        {
-            const int m = kk == 0 ? 2 : kk == 1 ? 0 : kk == 2 ? 3 : kk == 3 ? 7 : kk == 4 ? 1 : kk == 5 ? 8 : kk == 6 ? 4 : kk == 7 ? 6 : 5;
-            const int ok = kk == 0 ? 1 : kk <= 3 ? have_t : kk <= 5 ? have_l : have_all;
-            const int sad = v64_read(qs, 4*kk) + (m != mpred ? penalty : 0);
-            if (ok && (kk == 0 || sad < best_sad)) { best = kk; best_sad = sad; }
-        }
-        v64_each(row, [&](int l, int r) { if ((l >> 2) == best) lds32_store(pred + 16*(l & 3), (uint32_t)r); });
-        wave_sync();
-    }
-    const int bm = best == 0 ? 2 : best == 1 ? 0 : best == 2 ? 3 : best == 3 ? 7 : best == 4 ? 1 : best == 5 ? 8 : best == 6 ? 4 : best == 7 ? 6 : 5;
-    return bm + (best_sad << 4);
+    wave_sync();
+    const V64 row = v64_map(sel, [&](int l, int o) -> int {
+        const int k = l >> 2;
+        if (k >= 9) return 0;
+        if (k == 0) return (int)((uint32_t)dc*0x01010101u);
+        const uint32_t u = (uint32_t)o;
+        return (int)((uint32_t)S.pool[u & 255] | ((uint32_t)S.pool[(u >> 8) & 255] << 8) | ((uint32_t)S.pool[(u >> 16) & 255] << 16) | ((uint32_t)S.pool[u >> 24] << 24));
+    });
+    const V64 qs = v64_quad_sum(v64_map(row, [&](int l, int r) -> int { return (l >> 2) < 9 ? (int)sad4_u8(lds32(in + 16*(l & 3)), (uint32_t)r, 0) : 0; }));
+    /* cost << 4 | slot; a mode whose neighbours are missing cannot win (H:1834-1960: DC always, V DDL VL need the top, H HU the left, the rest all three) */
+    const V64 key = v64_map(qs, [&](int l, int sad) -> int {
+        const int k = l >> 2;
+        if (k >= 9) return 0x7fffffff;
+        const int need = k == 0 ? 0 : k <= 3 ? AV_T : k <= 5 ? AV_L : (AV_T | AV_L | AV_TL);
+        if ((avail & need) != need) return 0x7fffffff;
+        return ((sad + (i4_slot_mode(k) != mpred ? penalty : 0)) << 4) | k;
+    });
+    const V64 rm = v64_row_quadmin(key);
+    const int bk = imin(imin(v64_read(rm, 0), v64_read(rm, 16)), v64_read(rm, 32));
+    const int best = bk & 15, best_cost = bk >> 4;
+    v64_each(row, [&](int l, int r) { if ((l >> 2) == best) lds32_store(pred + 16*(l & 3), (uint32_t)r); });
+    wave_sync();
+    return i4_slot_mode(best) + (best_cost << 4);
 }
 
 /* ------------------------------------------------------------------ 4x4 transforms in registers (V16 tiles, wave.h) */
@@ -809,108 +801,34 @@ DEV V16 v16_inv4x4(const V16 &c)
 /* ------------------------------------------------------------------ transform / quant */
 
 /*
- * H:2619-2636 h264e_transform_sub_quant_dequant for n x n blocks (n = mode >> 1): forward 4x4 core
- * transform of (inp - pred) (H:2385-2409), DC pick-off, dead-zone zeroing (H:2512-2534) and
- * quantization (H:2536-2597).  One lane per coefficient, 64 coefficients per pass.
- * Returns the non-zero block mask, first block in the highest bit.
- */
-DEV unsigned wave_xform_quant(const uint8_t *inp, const uint8_t *pred, int mode, qblk_t *q, int16_t *dc, const uint16_t *qdat)
-{
-    const int n = mode >> 1, i0 = mode & 1, nb = n*n;
-    /* forward transform (H:2374-2409) in registers, one block per 16-lane tile (wave.h V16): four blocks per pass */
-    for (int pass = 0; pass*V16_TILES < nb; pass++)
-    {
-        const V16 d = v16_make([&](int i, int tile) -> int {
-            const int b = imin(pass*V16_TILES + tile, nb - 1), bx = b & (n - 1), by = b >> (n >> 1), o = 64*by + 4*bx + 16*(i >> 2) + (i & 3);      /* n is 1, 2 or 4 */
-            return (int)inp[o] - (int)pred[o];
-        });
-        const V16 c = v16_fwd4x4(d);
-        v16_each(c, [&](int i, int tile, int v) { const int b = pass*V16_TILES + tile; if (b < nb) q[b].dq[i] = (int16_t)v; });
-    }
-    wave_sync();
-    if (i0)
-    {
-        WAVE_FOR(l) { if (l < nb) dc[l] = q[l].dq[0]; }
-    }
-    unsigned zmask = 0;
-    if (mode == QMODE_INTER || mode == QMODE_CHROMA)
-    {
-        /* per-block test against thr1; for inter also the 8x8-group test against thr2 */
-        unsigned big1 = 0, big2 = 0;    /* bit b set: block b has a coefficient outside [-thr, thr] */
-        for (int pass = 0; pass*64 < nb*16; pass++)
-        {
-            uint64_t m1 = wave_ballot([&](int l) -> int {
-                int idx = pass*64 + l, b = idx >> 4, i = idx & 15;
-                if (b >= nb || i < i0) return 0;
-                unsigned thr = qdat[QD_THR1 + (i & 7)];
-                return (unsigned)(q[b].dq[i] + (int)thr) > 2u*thr;
-            });
-            uint64_t m2 = mode == QMODE_INTER ? wave_ballot([&](int l) -> int {
-                int idx = pass*64 + l, b = idx >> 4, i = idx & 15;
-                if (b >= nb || i < i0) return 0;
-                unsigned thr = qdat[QD_THR2 + (i & 7)];
-                return (unsigned)(q[b].dq[i] + (int)thr) > 2u*thr;
-            }) : 0;
-            for (int k = 0; k < 4; k++)
-            {
-                if ((m1 >> (16*k)) & 0xffff) big1 |= 1u << (pass*4 + k);
-                if ((m2 >> (16*k)) & 0xffff) big2 |= 1u << (pass*4 + k);
-            }
-        }
-        zmask = ~big1 & ((1u << nb) - 1);
-        if (mode == QMODE_INTER)
-        {
-            const unsigned grp[4] = { 0x0033, 0x00CC, 0x3300, 0xCC00 };
-            for (int k = 0; k < 4; k++)
-                if ((~zmask & grp[k]) && !(big2 & grp[k])) zmask |= grp[k];
-        }
-    }
-    unsigned nzbits = 0;    /* bit b: block b has a non-zero quantized coefficient */
-    for (int pass = 0; pass*64 < nb*16; pass++)
-    {
-        uint64_t nzm = wave_ballot([&](int l) -> int {
-            int idx = pass*64 + l, b = idx >> 4, i = idx & 15;
-            if (b >= nb) return 0;
-            if (zmask & (1u << b)) { q[b].qv[i] = 0; return 0; }
-            if (i < i0) return 0;
-            int off = ((i & 1) + ((i >> 2) & 1))*2;            /* H:2366 g_idx2quant */
-            int c = q[b].dq[i], rnd = qdat[QD_RND];
-            if (c < 0) rnd = 0xFFFF - rnd;
-            int v = (c*(int)qdat[off] + rnd) >> 16;
-            q[b].qv[i] = (int16_t)v;
-            q[b].dq[i] = (int16_t)(v*(int)qdat[off + 1]);
-            return v != 0;
-        });
-        for (int k = 0; k < 4; k++)
-            if ((nzm >> (16*k)) & 0xffff) nzbits |= 1u << (pass*4 + k);
-    }
-    wave_sync();
-    unsigned mask = 0;
-    for (int b = 0; b < nb; b++) mask = (mask << 1) | ((nzbits >> b) & 1);
-    return mask;
-}
-
-/*
  * One intra 4x4 block behind its mode decision (H:4790-4811): residual of the input block `bin` (stride 16) against the
  * prediction `pred` (stride 16), forward transform, quantisation (H:2536-2597, no dead zone for intra blocks), inverse transform and
- * reconstruction into `rec` (stride rs) -- all in the registers of one 16-lane tile.  Leaves levels and dequantized coefficients in
- * q (mb_write codes the levels when the macroblock ends up intra 4x4).  Returns 1 when a level is non-zero.
+ * reconstruction into `rec` (stride rs) -- all in the registers of one 16-lane tile (the wave's four tiles run the same block; tile 0
+ * stores).  Leaves levels and dequantized coefficients in q (mb_write codes the levels when the macroblock ends up intra 4x4).
+ * Returns 1 when a level is non-zero.  K: the lane context and the lane's quantiser constants, made once per macroblock (i4q_make).
  */
-DEV unsigned i4_block_code(const uint8_t *bin, const uint8_t *pred, uint8_t *rec, int rs, qblk_t *q, const uint16_t *qdat)
+struct I4Q { V16C C; V16 qm, dqm; int rnd; };
+DEV I4Q i4q_make(const uint16_t *qdat)
 {
-    const V16 d = v16_make([&](int i, int) -> int { return (int)bin[16*(i >> 2) + (i & 3)] - (int)pred[16*(i >> 2) + (i & 3)]; });
-    const V16 c = v16_fwd4x4(d);
-    const int rnd = qdat[QD_RND];
-    const V16 lev = v16_map(c, [&](int i, int v) -> int {
-        const int off = ((i & 1) + ((i >> 2) & 1))*2;            /* H:2366 g_idx2quant */
-        return (v*(int)qdat[off] + (v < 0 ? 0xFFFF - rnd : rnd)) >> 16;
-    });
-    const V16 deq = v16_map(lev, [&](int i, int v) -> int { return (int16_t)(v*(int)qdat[((i & 1) + ((i >> 2) & 1))*2 + 1]); });
-    v16_each(lev, [&](int i, int, int v) { q->qv[i] = (int16_t)v; });
-    v16_each(deq, [&](int i, int, int v) { q->dq[i] = (int16_t)v; });
-    const unsigned coded = v16_nonzero_mask(v16_map(lev, [](int, int v) -> int { return (int16_t)v; })) != 0;
-    const V16 r = v16_inv4x4(deq);
-    v16_each(r, [&](int i, int, int v) { const int x = i >> 2, y = i & 3; rec[rs*y + x] = (uint8_t)clip255(v + (int)pred[16*y + x]); });
+    I4Q k;
+    k.C = v16c_make();
+    k.qm = v16_make(k.C, [&](int i, int) -> int { return (int)qdat[((i & 1) + ((i >> 2) & 1))*2]; });          /* H:2366 g_idx2quant */
+    k.dqm = v16_make(k.C, [&](int i, int) -> int { return (int)qdat[((i & 1) + ((i >> 2) & 1))*2 + 1]; });
+    k.rnd = qdat[QD_RND];
+    return k;
+}
+DEV unsigned i4_block_code(const I4Q &K, const uint8_t *bin, const uint8_t *pred, uint8_t *rec, int rs, qblk_t *q)
+{
+    const V16 d = v16_make(K.C, [&](int i, int) -> int { return (int)bin[16*(i >> 2) + (i & 3)] - (int)pred[16*(i >> 2) + (i & 3)]; });
+    const V16 c = v16_fwd4x4_c(K.C, d);
+    const int rnd = K.rnd;
+    const V16 lev = v16_map2(K.C, c, K.qm, [&](int, int v, int m) -> int { return (mul24(v, m) + (v < 0 ? 0xFFFF - rnd : rnd)) >> 16; });
+    const V16 deq = v16_map2(K.C, lev, K.dqm, [](int, int v, int m) -> int { return (int16_t)mul24(v, m); });
+    v16_each(K.C, lev, [&](int i, int tile, int v) { if (tile == 0) q->qv[i] = (int16_t)v; });
+    v16_each(K.C, deq, [&](int i, int tile, int v) { if (tile == 0) q->dq[i] = (int16_t)v; });
+    const unsigned coded = v16_nonzero_mask(v16_map(K.C, lev, [](int, int v) -> int { return (int16_t)v; })) != 0;
+    const V16 r = v16_inv4x4_c(K.C, deq);
+    v16_each(K.C, r, [&](int i, int tile, int v) { const int x = i >> 2, y = i & 3; if (tile == 0) rec[rs*y + x] = (uint8_t)clip255(v + (int)pred[16*y + x]); });
     wave_sync();
     return coded;
 }
@@ -977,32 +895,100 @@ DEV int quant_chroma_dc(qblk_t *q, int16_t *dc, int16_t *lev, const uint16_t *qd
 }
 
 /*
- * H:2638-2681 h264e_transform_add: out = clip(pred + inverse transform) for blocks whose mask bit (first
- * block in bit 31) is set, plain copy of pred otherwise.  One lane per sample; the inverse transform keeps
- * the reference's pass order (horizontal, then vertical) and int16 intermediates (H:2436-2489).
- * out may be LDS or global memory; pred has stride 16.
+ * mb_write's transform path in ONE register pass (h264-lab.h:2619-2636 + 2638-2681 as H:4423-4488 calls them): residual -> forward
+ * transform -> dead-zone tests -> quantiser -> dequantiser -> [DC path] -> inverse transform -> reconstruction, the coefficients never
+ * leaving the registers of their 16-lane tile between the steps (wave_xform_quant + wave_recon are four passes with LDS round trips and
+ * four wave syncs between them; the reference's order of operations is irrelevant: the stages are pure functions of the block).
+ * Blocks are dealt to the passes by 8x8 GROUP -- pass g = the four blocks of group g, one per tile -- because the inter dead zone works
+ * on groups (H:2512-2534: a group whose blocks all stay inside the second threshold set is zeroed as a whole): the group test is one
+ * ballot of the pass, the per-block test one per tile.  MODE as wave_xform_quant: QMODE_INTER / QMODE_I16 (4 x 4 blocks) or
+ * QMODE_CHROMA (2 x 2 blocks = one group).  Leaves levels and dequantised coefficients in q as the reference does (CAVLC reads the
+ * levels; the dequantised ones only matter to the stage fixtures, which compare the whole array with the reference's).
+ * Returns the non-zero block mask, first block in the highest of the nb bits; *dc_nonzero: quant_chroma_dc's flag (QMODE_CHROMA).
  */
-DEV void wave_recon(uint8_t *out, int os, const uint8_t *pred, const qblk_t *q, int side, uint32_t mask)
+DEV int xq_block(int n, int g, int k) { return n == 4 ? 4*(2*(g >> 1) + (k >> 1)) + 2*(g & 1) + (k & 1) : k; }
+
+template <int MODE> DEV unsigned wave_xform_quant_recon(const uint8_t *inp, const uint8_t *pred, uint8_t *out, int os, qblk_t *q, int16_t *dc, int16_t *lev_dc,
+                                                        const uint16_t *qdat, int *dc_nonzero)
 {
-    const int nb = side*side;
-    for (int pass = 0; pass*V16_TILES < nb; pass++)
+    constexpr int n = MODE >> 1, i0 = MODE & 1, nb = n*n, NG = n == 4 ? 4 : 1, SUB = 4/V16_TILES;
+    constexpr bool dead_zone = MODE == QMODE_INTER || MODE == QMODE_CHROMA;
+    const V16C C = v16c_make();              /* the lane's position and transform constants, once for the whole pass (wave.h) */
+    /* what a lane needs of the quantiser tables never changes from pass to pass: coefficient position i = lane & 15 */
+    const V16 qm = v16_make(C, [&](int i, int) -> int { return (int)qdat[((i & 1) + ((i >> 2) & 1))*2]; });            /* H:2366 g_idx2quant */
+    const V16 dqm = v16_make(C, [&](int i, int) -> int { return (int)qdat[((i & 1) + ((i >> 2) & 1))*2 + 1]; });
+    const V16 th1 = v16_make(C, [&](int i, int) -> int { return dead_zone ? (int)qdat[QD_THR1 + (i & 7)] : 0; });
+    const V16 th2 = v16_make(C, [&](int i, int) -> int { return MODE == QMODE_INTER ? (int)qdat[QD_THR2 + (i & 7)] : 0; });
+    const int rnd = qdat[QD_RND];
+    V16 keep[NG*SUB];                        /* dequantised coefficients of the modes whose DC takes a path of its own before the reconstruction */
+    unsigned mask = 0;
+    const auto recon = [&](int g, int s, const V16 &deq) {
+        const V16 r = v16_inv4x4_c(C, deq);       /* sample (x, y) of the block in lane 4*x + y */
+        v16_each(C, r, [&](int i, int tile, int v) {
+            const int b = xq_block(n, g, s*V16_TILES + tile), bx = b & (n - 1), by = b >> (n >> 1), x = i >> 2, y = i & 3;
+            out[(size_t)(4*by + y)*os + 4*bx + x] = (uint8_t)clip255(v + (int)pred[64*by + 4*bx + 16*y + x]);
+        });
+    };
+#pragma unroll
+    for (int g = 0; g < NG; g++)
     {
-        /* one block per 16-lane tile; v16_inv4x4 leaves sample (x, y) in lane 4*x + y */
-        const V16 c = v16_make([&](int i, int tile) -> int {
-            const int b = imin(pass*V16_TILES + tile, nb - 1);
-            return ((mask << b) & 0x80000000u) ? (int)q[b].dq[i] : 0;
-        });
-        const V16 r = v16_inv4x4(c);
-        v16_each(r, [&](int i, int tile, int v) {
-            const int b = pass*V16_TILES + tile;
-            if (b < nb)
+        V16 c[SUB], own[SUB];
+        int any1 = 0, any2 = 0;
+#pragma unroll
+        for (int s = 0; s < SUB; s++)
+        {
+            const V16 d = v16_make(C, [&](int i, int tile) -> int {
+                const int b = xq_block(n, g, s*V16_TILES + tile), bx = b & (n - 1), by = b >> (n >> 1), o = 64*by + 4*bx + 16*(i >> 2) + (i & 3);
+                return (int)inp[o] - (int)pred[o];
+            });
+            c[s] = v16_fwd4x4_c(C, d);
+            if (i0) v16_each(C, c[s], [&](int i, int tile, int v) { if (i == 0) dc[xq_block(n, g, s*V16_TILES + tile)] = (int16_t)v; });
+            if (dead_zone)
             {
-                const int x = i >> 2, y = i & 3, bx = b & (side - 1), by = b >> (side >> 1);          /* side is 1, 2 or 4 */
-                out[(size_t)(4*by + y)*os + 4*bx + x] = (uint8_t)clip255(v + (int)pred[64*by + 4*bx + 16*y + x]);      /* no coded coefficients: v = 0, the prediction */
+                /* H:2491-2534: a coefficient outside [-thr, thr] keeps its block (first set) / its 8x8 group (second set) alive */
+                const V16 f1 = v16_map2(C, c[s], th1, [](int i, int v, int t) -> int { return i >= i0 && (unsigned)(v + t) > 2u*(unsigned)t; });
+                own[s] = v16_tile_any(C, f1);
+                any1 |= v16_any(f1);
+                if (MODE == QMODE_INTER) any2 |= v16_any(v16_map2(C, c[s], th2, [](int, int v, int t) -> int { return (unsigned)(v + t) > 2u*(unsigned)t; }));
             }
-        });
+        }
+        const int group_zero = MODE == QMODE_INTER && any1 && !any2;
+#pragma unroll
+        for (int s = 0; s < SUB; s++)
+        {
+            const V16 keepb = dead_zone ? (group_zero ? v16_splat(0) : own[s]) : v16_splat(1);       /* per lane: is my block quantised at all? */
+            const V16 lev = v16_map3(C, c[s], qm, keepb, [&](int i, int v, int m, int k) -> int {
+                return (k && i >= i0) ? (mul24(v, m) + (v < 0 ? 0xFFFF - rnd : rnd)) >> 16 : 0;      /* H:2570-2574; |v| < 2^15, m < 2^16 */
+            });
+            const V16 deq = v16_map2(C, lev, dqm, [](int, int v, int m) -> int { return (int16_t)mul24(v, m); });
+            /* q as the reference leaves it: levels (zero in a zeroed block); dequantised coefficients -- the transform coefficient itself
+             * where the quantiser did not run (zeroed blocks, and the DC position the DC path is about to replace) */
+            v16_each(C, lev, [&](int i, int tile, int v) { q[xq_block(n, g, s*V16_TILES + tile)].qv[i] = (int16_t)v; });
+            const V16 dq_store = v16_map3(C, deq, c[s], keepb, [](int i, int dv, int cv, int k) -> int { return (k && i >= i0) ? dv : cv; });
+            v16_each(C, dq_store, [&](int i, int tile, int v) { q[xq_block(n, g, s*V16_TILES + tile)].dq[i] = (int16_t)v; });
+            const unsigned nzt = v16_tiles_nonzero(v16_map(C, lev, [](int, int v) -> int { return (int16_t)v; }));
+            for (int t = 0; t < V16_TILES; t++) if ((nzt >> t) & 1) mask |= 1u << (nb - 1 - xq_block(n, g, s*V16_TILES + t));
+            if (MODE == QMODE_INTER) recon(g, s, deq);
+            else keep[g*SUB + s] = deq;
+        }
+    }
+    if (MODE != QMODE_INTER)
+    {
+        wave_sync();                        /* dc[] is complete */
+        if (MODE == QMODE_I16) quant_luma_dc(q, dc, lev_dc, qdat);
+        else *dc_nonzero = quant_chroma_dc(q, dc, lev_dc, qdat);
+        /* the DC path has left every block's dequantised DC in q[b].dq[0] (both end with a wave sync) */
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int s = 0; s < SUB; s++)
+            {
+                const V16 dcv = v16_make(C, [&](int i, int tile) -> int { return i == 0 ? (int)q[xq_block(n, g, s*V16_TILES + tile)].dq[0] : 0; });
+                recon(g, s, v16_map2(C, keep[g*SUB + s], dcv, [](int i, int a, int d) -> int { return i == 0 ? d : a; }));
+            }
     }
     wave_sync();
+    return mask;
 }
 
 /* ------------------------------------------------------------------ CAVLC (uniform) */

@@ -734,7 +734,8 @@ template <class BOUND> DEV int intra4_choose(RowLds &L, MbBuf &B, const MbCtx &m
     int cost = m.lambda_i4;
     unsigned nz_mask = 0;
     if (cost >= bound()) return I4_LOST;
-    const V64 lut01 = i4_lut_lanes(L.i4s, 0), lut23 = i4_lut_lanes(L.i4s, 1);      /* every lane's own prediction-table entries, for all 16 blocks */
+    const V64 sel = i4_sel_lanes();                                                 /* every lane's own prediction-table entry, for all 16 blocks */
+    const I4Q K = i4q_make(L.qdat[0]);                                              /* ... and its quantiser / transform constants */
     WAVE_FOR(l)
     {
         if (l < 16) { r0[-24 + l] = B.pix_top[l]; r0[24*l - 1] = L.pix_left[l]; }
@@ -756,7 +757,7 @@ template <class BOUND> DEV int intra4_choose(RowLds &L, MbBuf &B, const MbCtx &m
         int mpred = imin(L.i4_left[r], B.i4_top[c]);
         if (mpred < 0) mpred = 2;
         STAMP(L, 19);
-        int res = wave_i4_choose(bin, pr, a, blk - 24, blk - 1, 24, mpred, MUL_LAMBDA(3, m.lambda_q4), L.i4s, lut01, lut23);
+        int res = wave_i4_choose(bin, pr, a, blk, 24, mpred, MUL_LAMBDA(3, m.lambda_q4), L.i4s, sel);
         STAMP(L, 31);
         const int mode = res & 15, sad = res >> 4;
         L.i4_left[r] = B.i4_top[c] = (int8_t)mode;
@@ -764,7 +765,7 @@ template <class BOUND> DEV int intra4_choose(RowLds &L, MbBuf &B, const MbCtx &m
         unsigned coded = 0;
         cost += sad;
         if (cost >= bound()) return I4_LOST;
-        if (sad > m.skip_thr_i4) coded = i4_block_code(bin, pr, blk, 24, L.qy + n, L.qdat[0]);     /* transform, quantiser, reconstruction -> working picture */
+        if (sad > m.skip_thr_i4) coded = i4_block_code(K, bin, pr, blk, 24, L.qy + n);     /* transform, quantiser, reconstruction -> working picture */
         else
         {
             WAVE_FOR(l)
@@ -866,14 +867,10 @@ DEV void mb_write(RowLds &L, MbBuf &B, MbCtx &m, BitW &b)
         PTIC();
         if (m.type != 5)
         {
-            unsigned mask = wave_xform_quant(B.inp, B.pred, i16 ? QMODE_I16 : QMODE_INTER, L.qy, L.dcy, L.qdat[0]);
+            /* residual -> transform -> dead zone -> quantiser -> [luma DC] -> reconstruction in one register pass per 8x8 group (enc_kernels.h) */
+            const unsigned mask = i16 ? wave_xform_quant_recon<QMODE_I16>(B.inp, B.pred, ty, YT_STRIDE, L.qy, L.dcy, L.lev_dcy, L.qdat[0], (int *)0)
+                                      : wave_xform_quant_recon<QMODE_INTER>(B.inp, B.pred, ty, YT_STRIDE, L.qy, L.dcy, L.lev_dcy, L.qdat[0], (int *)0);
             m.nz_mask = mask & 0xffff;
-            if (i16)
-            {
-                quant_luma_dc(L.qy, L.dcy, L.lev_dcy, L.qdat[0]);
-                mask = 0xFFFF;
-            }
-            wave_recon(ty, YT_STRIDE, B.pred, L.qy, 4, mask << 16);
         } else
         {
             WAVE_FOR(l)
@@ -891,24 +888,13 @@ DEV void mb_write(RowLds &L, MbBuf &B, MbCtx &m, BitW &b)
 
         for (int c = 0; c < 2; c++)
         {
-            qblk_t *q = c ? L.qv : L.qu;
-            int16_t *dc = c ? L.dcv : L.dcu;
-            unsigned mask = wave_xform_quant(B.inp_c + 8*c, L.pred_c + 8*c, QMODE_CHROMA, q, dc, L.qdat[1]);
+            /* H:4453-4488: chroma AC with the dead zone, the 2x2 DC transform, reconstruction of every block once a DC level is coded (the
+             * dequantised AC of a block without coded levels is zero in the registers: the reference zeroes its array for the same effect) */
+            int dc_flag = 0;
+            const unsigned mask = wave_xform_quant_recon<QMODE_CHROMA>(B.inp_c + 8*c, L.pred_c + 8*c, tc[c], CT_STRIDE, c ? L.qv : L.qu, c ? L.dcv : L.dcu,
+                                                                       c ? L.lev_dcv : L.lev_dcu, L.qdat[1], &dc_flag);
             if (mask) cbpc = 2;
-            const int dc_flag = quant_chroma_dc(q, dc, c ? L.lev_dcv : L.lev_dcu, L.qdat[1]);
             cbpc |= dc_flag;
-            if (dc_flag)
-            {
-                const unsigned am = mask;
-                WAVE_FOR(l)
-                {
-                    int blk4 = l >> 4, i = l & 15;
-                    if (i && (~am & (8u >> blk4))) q[blk4].dq[i] = 0;
-                }
-                wave_sync();
-                mask = 15;
-            }
-            wave_recon(tc[c], CT_STRIDE, L.pred_c + 8*c, q, 2, mask << 28);
         }
         cbpc = imin(cbpc, 2);
         /* roll back to skip (H:4493-4499) */

@@ -68,7 +68,6 @@ DEV void row_begin(RowLds &L, const h264e_geom_t &G, const ChainG &C, const h264
     WAVE_FOR(l)
     {
         for (int k = l; k < 84; k += 64) L.qdat[k/42][k%42] = T.qdat[k/42][k%42];
-        for (int k = l; k < 144; k += 64) L.i4s.lut[k] = k_i4_lut[k/16][k%16];
     }
     cavlc_tab_load(L.cavlc);
     df_tab_load(L.dftab);
@@ -304,7 +303,7 @@ template <int GEOM, class HOOK> DEV void mb_recon_front(RowLds &L, MbBuf &B, MbC
     after_prediction();             /* two waves per row: the `decided` counter (h264e_kernels.hip) */
 
     STAMP(L, 10);
-    BitW bw = L.bw;
+    BitW bw = bw_uniform(L.bw);
     mb_write(L, B, m, bw);
     L.bw = bw;
     STAMP(L, 11);
@@ -504,7 +503,7 @@ template <int GEOM> DEV void row_step(RowLds &L, const h264e_geom_t &G, const Ch
 
 DEV void row_end(RowLds &L, const h264e_geom_t &G, const ChainG &C, int row)
 {
-    BitW bw = L.bw;
+    BitW bw = bw_uniform(L.bw);
     const uint32_t nbits = bw_bits(bw);
     if (bw.nacc)
     {

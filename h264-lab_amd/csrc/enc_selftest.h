@@ -85,34 +85,22 @@ DEV void stage_selftest(StageLds &S, RowLds &L, int stage, const GLOBAL_AS uint8
             for (int k = l; k < 256; k += 64) lds32_store((uint8_t *)S.q + 4*k, 0u);
         }
         wave_sync();
-        unsigned nz = wave_xform_quant(S.a, S.b, mode, S.q, S.dc, S.qdat);
+        /* the product's paths: mb_write's fused pass (transform -> dead zone -> quantiser -> DC path -> reconstruction) for the inter, intra 16x16
+         * and chroma modes, intra4_choose's block coder for the intra 4x4 mode; q (levels + dequantised coefficients), the DC levels and the
+         * reconstruction are what the reference's functions leave (h264-lab.h:2619-2681, 4428-4433, 4468-4488, 4809-4811) */
+        unsigned nz = 0;
         int dcflag = 0;
+        WAVE_FOR(l) { lds32_store(S.o + 4*l, lds32(S.b + 4*l)); }
         wave_sync();
-        if (mode == QMODE_I16) quant_luma_dc(S.q, S.dc, S.lev, S.qdat);
-        if (mode == QMODE_CHROMA) dcflag = quant_chroma_dc(S.q, S.dc, S.lev, S.qdat);
+        if (mode == QMODE_INTER) nz = wave_xform_quant_recon<QMODE_INTER>(S.a, S.b, S.o, 16, S.q, S.dc, S.lev, S.qdat, (int *)0);
+        else if (mode == QMODE_I16) nz = wave_xform_quant_recon<QMODE_I16>(S.a, S.b, S.o, 16, S.q, S.dc, S.lev, S.qdat, (int *)0);
+        else if (mode == QMODE_CHROMA) nz = wave_xform_quant_recon<QMODE_CHROMA>(S.a, S.b, S.o, 16, S.q, S.dc, S.lev, S.qdat, &dcflag);
+        else nz = i4_block_code(i4q_make(S.qdat), S.a, S.b, S.o, 16, S.q);
         wave_sync();
-        /* the operands as the reference has them in front of the reconstruction */
         WAVE_FOR(l)
         {
             for (int k = l; k < 256; k += 64) gstore32((gu8 *)out + 8 + 4*k, lds32((const uint8_t *)S.q + 4*k));
             if (l < 8) { gstore32((gu8 *)out + 8 + 1024 + 4*l, lds32((const uint8_t *)S.dc + 4*l)); gstore32((gu8 *)out + 8 + 1056 + 4*l, lds32((const uint8_t *)S.lev + 4*l)); }
-        }
-        /* reconstruction as mb_write / intra4_choose call it (h264-lab.h:4428-4433, 4468-4488, 4809-4811) */
-        WAVE_FOR(l) { lds32_store(S.o + 4*l, lds32(S.b + 4*l)); }
-        wave_sync();
-        if (mode == QMODE_INTER) wave_recon(S.o, 16, S.b, S.q, 4, nz << 16);
-        else if (mode == QMODE_I16) wave_recon(S.o, 16, S.b, S.q, 4, 0xffffu << 16);
-        else if (mode == QMODE_I4) { if (nz & 1) wave_recon(S.o, 16, S.b, S.q, 1, 0x80000000u); }
-        else if (dcflag | (int)nz)
-        {
-            unsigned m = nz;
-            if (dcflag)
-            {
-                WAVE_FOR(l) { if (l < 60) { const int b4 = l/15, i = 1 + l % 15; if (~nz & (8u >> b4)) S.q[b4].dq[i] = 0; } }
-                wave_sync();
-                m = 15;
-            }
-            wave_recon(S.o, 16, S.b, S.q, 2, m << 28);
         }
         wave_sync();
         WAVE_FOR(l) { gstore32((gu8 *)out + 8 + 1088 + 4*l, lds32(S.o + 4*l)); }
@@ -133,7 +121,6 @@ DEV void stage_selftest(StageLds &S, RowLds &L, int stage, const GLOBAL_AS uint8
     {
         WAVE_FOR(l)
         {
-            for (int k = l; k < 144; k += 64) S.i4s.lut[k] = k_i4_lut[k/16][k%16];
             if (l < 13)
             {
                 const uint8_t e = in[l];
@@ -144,8 +131,7 @@ DEV void stage_selftest(StageLds &S, RowLds &L, int stage, const GLOBAL_AS uint8
             if (l < 16) lds32_store(S.o + 4*l, 0u);
         }
         wave_sync();
-        const V64 lut01 = i4_lut_lanes(S.i4s, 0), lut23 = i4_lut_lanes(S.i4s, 1);
-        const int res = wave_i4_choose(S.a, S.o, a[0], S.nb + 4, S.nb + 24 + 3, 24, a[1], a[2], S.i4s, lut01, lut23);
+        const int res = wave_i4_choose(S.a, S.o, a[0], S.nb + 24 + 4, 24, a[1], a[2], S.i4s, i4_sel_lanes());
         wave_sync();
         WAVE_FOR(l) { if (l < 16) gstore32((gu8 *)out + 8 + 4*l, lds32(S.o + 4*l)); }
         if (wave_lane() == 0) { oi[0] = res & 15; oi[1] = res >> 4; }

@@ -153,6 +153,12 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
     {
         /* ---- finalizer (one wavefront; the second one of a two-wave workgroup has nothing to do here) */
         if (wv) return;
+#ifdef H264E_STAMPS
+        unsigned long long fz_t = wall_clock64();
+#define FZ_STAMP(id) do { const unsigned long long n_ = wall_clock64(); if (LANE == 0 && C.prof) atomicAdd(C.prof + (id), n_ - fz_t); fz_t = n_; } while (0)
+#else
+#define FZ_STAMP(id) do { } while (0)
+#endif
         int st = 0, seen = 0;
         GLOBAL_AS h264e_hostdone_t *hd = (GLOBAL_AS h264e_hostdone_t *)T.host_done;
         GLOBAL_AS h264e_walkrec_t *wout = (GLOBAL_AS h264e_walkrec_t *)T.walk_out;
@@ -177,6 +183,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        FZ_STAMP(32);               /* waited for the frame's rows */
         int wstatus = 0, first_bad = -1;
         mv32 ws[2] = { T.exact_state[0], T.exact_state[1] };
         if (T.walk_on_device)
@@ -197,11 +204,13 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
                     else { ws[0] = (mv32)uni(wp->state_out[0]); ws[1] = (mv32)uni(wp->state_out[1]); }
                 }
             }
+            FZ_STAMP(33);           /* waited for the verdict of the frame in front */
             if (!wstatus)
             {
                 first_bad = device_clusters_walk(G, T, C.mbrec + (size_t)T.frame_slot*G.nmb, ws, (GLOBAL_AS mv32 *)T.traj_out);
                 wstatus = first_bad >= 0 ? H264E_WALK_BAD : H264E_WALK_OK;
             }
+            FZ_STAMP(34);           /* the exact walk of the frame's records: the serial chain from frame to frame */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             if (LANE == 0 && wout)
@@ -229,6 +238,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
             }
         }
         finalize_frame(G, C, T, (GLOBAL_AS int *)T.stepflags);
+        FZ_STAMP(35);               /* slice splice */
         if (hd)
         {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
@@ -253,6 +263,10 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
                 __hip_atomic_store(&hd->done, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
+        FZ_STAMP(36);               /* NAL escaping + export to host-mapped memory */
+#ifdef H264E_STAMPS
+        if (LANE == 0 && C.prof) atomicAdd(C.prof + 37, 1ull);
+#endif
         return;
     }
 

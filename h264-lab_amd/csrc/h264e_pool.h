@@ -420,7 +420,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
             C.nal_cap = slots == 1 ? nal_cap : 0;
             C.cursor = (uint32_t *)carve(16, 256);
             C.fout = (h264e_frameout_t *)carve(sizeof(h264e_frameout_t)*(size_t)slots, 256);
-            C.prof = (unsigned long long *)carve(sizeof(unsigned long long)*32, 256);
+            C.prof = (unsigned long long *)carve(sizeof(unsigned long long)*48, 256);     /* 0..31 the rows' phases, 32..47 the finalizer's */
             C.far_reads = (int *)carve(16, 256);
             p->clu_dev[c] = (int32_t *)carve(sizeof(int32_t)*2*(size_t)G.nmb, 256);      /* per-macroblock mv_clusters array of a re-encode */
             p->traj_dev[c] = slots == 1 ? (int32_t *)carve(sizeof(int32_t)*4*(size_t)G.nmb, 256) : 0;   /* two walk trajectories (device-side validation) */
@@ -1272,18 +1272,19 @@ extern "C" int h264e_hip_selftest_stage(h264e_hip_pool_t *p, int stage, const ui
     return 0;
 }
 
-/* diagnostic: per-phase cycle sums of the -DH264E_STAMPS build, summed over chains (zeros in the product build) */
-extern "C" int h264e_hip_stamps_read(h264e_hip_pool_t *p, unsigned long long *dst /* [32] */, int reset)
+/* diagnostic: per-phase cycle sums of the -DH264E_STAMPS build, summed over chains (zeros in the product build): [0..31] the rows'
+ * phases, [32..47] the finalizer workgroups' (10 ns ticks of the constant 100 MHz clock) */
+extern "C" int h264e_hip_stamps_read(h264e_hip_pool_t *p, unsigned long long *dst /* [48] */, int reset)
 {
     if (!p || !dst) FAIL("stamps_read: bad argument");
-    memset(dst, 0, 32*sizeof(unsigned long long));
+    memset(dst, 0, 48*sizeof(unsigned long long));
     for (int c = 0; c < p->nchains; c++)
     {
-        unsigned long long t[32];
+        unsigned long long t[48];
         HIPCHK(hipSetDevice(p->device));
         HIPCHK(hipMemcpy(t, p->chains_host[c].prof, sizeof(t), hipMemcpyDeviceToHost));
         if (reset) HIPCHK(hipMemset(p->chains_host[c].prof, 0, sizeof(t)));
-        for (int i = 0; i < 32; i++) dst[i] += t[i];
+        for (int i = 0; i < 48; i++) dst[i] += t[i];
     }
     return 0;
 }

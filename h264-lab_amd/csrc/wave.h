@@ -132,7 +132,24 @@ DEV V16 v16_splat(int s) { V16 r; for (int i = 0; i < 16; i++) r.v[i] = s; retur
 template <class F> DEV V16 v16_make(F f) { V16 r; for (int i = 0; i < 16; i++) r.v[i] = f(i, 0); return r; }            /* r[i] = f(i, tile) */
 template <class F> DEV V16 v16_map(const V16 &a, F f) { V16 r; for (int i = 0; i < 16; i++) r.v[i] = f(i, a.v[i]); return r; }
 template <class F> DEV V16 v16_map2(const V16 &a, const V16 &b, F f) { V16 r; for (int i = 0; i < 16; i++) r.v[i] = f(i, a.v[i], b.v[i]); return r; }
+template <class F> DEV V16 v16_map3(const V16 &a, const V16 &b, const V16 &c, F f) { V16 r; for (int i = 0; i < 16; i++) r.v[i] = f(i, a.v[i], b.v[i], c.v[i]); return r; }
 template <class F> DEV void v16_each(const V16 &a, F f) { for (int i = 0; i < 16; i++) f(i, 0, a.v[i]); }                  /* f(i, tile, value): stores */
+/* does the wave hold a non-zero lane (uniform) / does MY tile hold one (per lane, 0 or 1) / which tiles do (bit t: tile t) */
+DEV int v16_any(const V16 &a) { for (int i = 0; i < 16; i++) if (a.v[i]) return 1; return 0; }
+DEV V16 v16_tile_any(const V16 &a) { V16 r; const int n = v16_any(a); for (int i = 0; i < 16; i++) r.v[i] = n; return r; }
+DEV unsigned v16_tiles_nonzero(const V16 &a) { return (unsigned)v16_any(a); }
+/* V16C (see the device build below): nothing to cache here; the context forms are the plain ones */
+struct V16C { };
+DEV V16C v16c_make() { return V16C(); }
+template <class F> DEV V16 v16_make(const V16C &, F f) { return v16_make(f); }
+template <class F> DEV V16 v16_map(const V16C &, const V16 &a, F f) { return v16_map(a, f); }
+template <class F> DEV V16 v16_map2(const V16C &, const V16 &a, const V16 &b, F f) { return v16_map2(a, b, f); }
+template <class F> DEV V16 v16_map3(const V16C &, const V16 &a, const V16 &b, const V16 &c, F f) { return v16_map3(a, b, c, f); }
+template <class F> DEV void v16_each(const V16C &, const V16 &a, F f) { v16_each(a, f); }
+DEV V16 v16_tile_any(const V16C &, const V16 &a) { return v16_tile_any(a); }
+/* (the transforms themselves: enc_kernels.h v16_fwd4x4 / v16_inv4x4, found at the point of instantiation) */
+template <class V> DEV V v16_fwd4x4_c(const V16C &, const V &d) { return v16_fwd4x4(d); }
+template <class V> DEV V v16_inv4x4_c(const V16C &, const V &c) { return v16_inv4x4(c); }
 template <int P0, int P1, int P2, int P3> DEV V16 v16_quadperm(const V16 &a)
 {
     const int p[4] = { P0, P1, P2, P3 };
@@ -151,6 +168,7 @@ template <class P> DEV P uniptr(P p) { return p; }
 DEV uint32_t alignbyte32(uint32_t hi, uint32_t lo, unsigned sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8*(sh & 3))); }
 DEV uint32_t ld32_aligned(const void *q) { uint32_t v; memcpy(&v, q, 4); return v; }
 DEV int opaque_int(int v) { return v; }
+DEV int mul24(int a, int b) { return a*b; }           /* product of two values of at most 24 bits (the device build has a full-rate instruction for it) */
 DEV int popc32(uint32_t v) { return __builtin_popcount(v); }
 /* a progress counter of another workgroup: the emulation runs producers to completion before their consumers, so it is always there */
 DEV int dep_poll(const int *p) { EMU_GLOBAL(p, 4); return 0x7fffffff; }
@@ -168,6 +186,17 @@ template <class F> DEV void v64_each(const V64 &a, F f) { WAVE_FOR(l) f(l, a.v[l
 DEV V64 v64_quad_sum(const V64 &a) { V64 r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l & ~3] + a.v[(l & ~3) + 1] + a.v[(l & ~3) + 2] + a.v[(l & ~3) + 3]; return r; }
 DEV int v64_read(const V64 &a, int lane) { return a.v[lane]; }
 DEV int v64_own(const V64 &a, int lane) { return a.v[lane]; }          /* inside a lane section: this lane's own value */
+template <class F> DEV void v64_each3(const V64 &a, const V64 &b, const V64 &c, F f) { WAVE_FOR(l) f(l, a.v[l], b.v[l], c.v[l]); }
+/* the value of the lane below / above inside the 16-lane row; the row's first / last lane keeps its own */
+DEV V64 v64_row_shr1(const V64 &a) { V64 r; for (int l = 0; l < 64; l++) r.v[l] = (l & 15) ? a.v[l - 1] : a.v[l]; return r; }
+DEV V64 v64_row_shl1(const V64 &a) { V64 r; for (int l = 0; l < 64; l++) r.v[l] = (l & 15) != 15 ? a.v[l + 1] : a.v[l]; return r; }
+/* minimum over the four quads of the 16-lane row, position by position inside the quad */
+DEV V64 v64_row_quadmin(const V64 &a)
+{
+    V64 r;
+    for (int l = 0; l < 64; l++) { int m = a.v[l]; for (int q = 0; q < 4; q++) { const int v = a.v[(l & 48) | (4*q) | (l & 3)]; if (v < m) m = v; } r.v[l] = m; }
+    return r;
+}
 DEV uint64_t v64_nonzero_ballot(const V64 &a) { uint64_t m = 0; for (int l = 0; l < 64; l++) if (a.v[l]) m |= 1ull << l; return m; }
 #define PROF_ROW_BEGIN(L) do { } while (0)
 #define PROF_ROW_SYNC(L) do { } while (0)
@@ -181,6 +210,7 @@ DEV uint64_t v64_nonzero_ballot(const V64 &a) { uint64_t m = 0; for (int l = 0; 
 /* OPAQUE to the optimiser on purpose: with a plain expression the compiler computes every lane-dependent LDS address of the macroblock
  * loop once, in front of the loop, and keeps the lot alive in registers across the whole loop body (measured: two-wave kernel 168 VGPRs +
  * 61 spilled -> 164 and none; at 128 VGPRs 114 spilled -> 30; SGPR spills 289 -> 178).  Recomputing an address costs an instruction or two. */
+static __device__ __forceinline__ int imin_raw(int a, int b) { return a < b ? a : b; }
 static __device__ __forceinline__ int lane_opaque() { int l = (int)(threadIdx.x & 63u); asm volatile("" : "+v"(l)); return l; }
 #define LANE lane_opaque()
 #define GLOBAL_AS __attribute__((address_space(1)))
@@ -314,7 +344,25 @@ DEV V16 v16_splat(int s) { V16 r; r.v = s; return r; }
 template <class F> DEV V16 v16_make(F f) { V16 r; r.v = f(LANE & 15, LANE >> 4); return r; }
 template <class F> DEV V16 v16_map(const V16 &a, F f) { V16 r; r.v = f(LANE & 15, a.v); return r; }
 template <class F> DEV V16 v16_map2(const V16 &a, const V16 &b, F f) { V16 r; r.v = f(LANE & 15, a.v, b.v); return r; }
+template <class F> DEV V16 v16_map3(const V16 &a, const V16 &b, const V16 &c, F f) { V16 r; r.v = f(LANE & 15, a.v, b.v, c.v); return r; }
 template <class F> DEV void v16_each(const V16 &a, F f) { f(LANE & 15, LANE >> 4, a.v); }
+/* does the wave hold a non-zero lane (uniform) / does MY tile hold one (per lane, 0 or 1) / which tiles do (bit t: tile t): one ballot each */
+DEV int v16_any(const V16 &a) { return __ballot(a.v != 0) != 0; }
+DEV V16 v16_tile_any(const V16 &a)
+{
+    const unsigned long long m = __ballot(a.v != 0);
+    const int t = LANE >> 4;
+    const unsigned w = (t & 2) ? (unsigned)(m >> 32) : (unsigned)m;
+    V16 r;
+    r.v = ((w >> (16*(t & 1))) & 0xffffu) != 0;
+    return r;
+}
+DEV unsigned v16_tiles_nonzero(const V16 &a)
+{
+    const unsigned long long m = __ballot(a.v != 0);
+    const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+    return ((lo & 0xffffu) ? 1u : 0u) | ((lo >> 16) ? 2u : 0u) | ((hi & 0xffffu) ? 4u : 0u) | ((hi >> 16) ? 8u : 0u);
+}
 template <int P0, int P1, int P2, int P3> DEV V16 v16_quadperm(const V16 &a)
 {
     V16 r;
@@ -333,6 +381,74 @@ DEV V16 v16_from(const V16 &a, const V16 &idx)
     r.v = __builtin_amdgcn_ds_bpermute(4*((LANE & 48) | (idx.v & 15)), a.v);
     return r;
 }
+/*
+ * V16C: what a lane needs again and again inside one V16 kernel -- its position in the tile, and the per-lane constants of the 4x4
+ * transforms -- computed ONCE from the (opaque) lane id.  The plain forms above read the lane id anew in every call, which is what keeps
+ * the compiler from hoisting lane-dependent values out of the macroblock loop (lane_opaque) -- and costs a dozen instructions per call;
+ * a kernel that runs many V16 steps back to back (mb_write's fused transform pass, the intra 4x4 block coder) makes one context and
+ * hands it to the context forms below: their lane-dependent values are ordinary values the compiler shares inside that kernel.
+ */
+struct V16C
+{
+    int i, tile;                /* lane & 15, lane >> 4 */
+    int xp;                     /* ds_bpermute address of the transposed position inside the tile */
+    int f_s, f_ka, f_kb;        /* forward pass: u = partner + f_s*own; out = f_ka*A + f_kb*B */
+    int i_sh, i_a1, i_a2, i_s;  /* inverse pass: u = i_a1*(own >> i_sh) + i_a2*partner; out = A + i_s*B */
+};
+DEV V16C v16c_make()
+{
+    V16C c;
+    const int l = LANE, x = l & 3;
+    c.i = l & 15; c.tile = l >> 4;
+    c.xp = 4*((l & 48) | ((l & 3) << 2) | ((l >> 2) & 3));
+    c.f_s = (x & 2) ? -1 : 1;
+    c.f_ka = x == 1 ? 2 : 1; c.f_kb = x == 0 ? 1 : x == 1 ? 1 : x == 2 ? -1 : -2;
+    c.i_sh = x & 1; c.i_a1 = x == 2 ? -1 : 1; c.i_a2 = x == 1 ? -1 : 1; c.i_s = (x & 2) ? -1 : 1;
+    return c;
+}
+template <class F> DEV V16 v16_make(const V16C &c, F f) { V16 r; r.v = f(c.i, c.tile); return r; }
+template <class F> DEV V16 v16_map(const V16C &c, const V16 &a, F f) { V16 r; r.v = f(c.i, a.v); return r; }
+template <class F> DEV V16 v16_map2(const V16C &c, const V16 &a, const V16 &b, F f) { V16 r; r.v = f(c.i, a.v, b.v); return r; }
+template <class F> DEV V16 v16_map3(const V16C &c, const V16 &a, const V16 &b, const V16 &d, F f) { V16 r; r.v = f(c.i, a.v, b.v, d.v); return r; }
+template <class F> DEV void v16_each(const V16C &c, const V16 &a, F f) { f(c.i, c.tile, a.v); }
+DEV V16 v16_tile_any(const V16C &c, const V16 &a)
+{
+    const unsigned long long m = __ballot(a.v != 0);
+    const unsigned w = (c.tile & 2) ? (unsigned)(m >> 32) : (unsigned)m;
+    V16 r;
+    r.v = ((w >> (16*(c.tile & 1))) & 0xffffu) != 0;
+    return r;
+}
+/* the 4x4 core transforms with the lane constants of the context: every step is a DPP move inside the quad and a 24-bit multiply-add
+ * with a per-lane coefficient (the operands are 16-bit quantities: v_mul_i32_i24 is exact and full rate), the other direction goes
+ * through one ds_bpermute transpose.  Same arithmetic as enc_kernels.h v16_fwd4x4 / v16_inv4x4, which state it in the open (the
+ * emulation build runs those; tests/test_stages.py holds both against the reference's own functions). */
+#define V16_DPP(v, p0, p1, p2, p3) __builtin_amdgcn_update_dpp(0, (v), (p0) | ((p1) << 2) | ((p2) << 4) | ((p3) << 6), 0xf, 0xf, true)
+DEV int v16_fwd_quad_c(const V16C &c, int d)
+{
+    const int u = V16_DPP(d, 3, 2, 1, 0) + __mul24(d, c.f_s);                    /* t0 = d0+d3, t2 = d1+d2, t3 = d1-d2, t1 = d0-d3 */
+    return __mul24(V16_DPP(u, 0, 3, 0, 3), c.f_ka) + __mul24(V16_DPP(u, 1, 2, 1, 2), c.f_kb);
+}
+DEV int v16_inv_quad_c(const V16C &c, int d)
+{
+    const int u = __mul24(d >> c.i_sh, c.i_a1) + __mul24(V16_DPP(d, 2, 3, 0, 1), c.i_a2);     /* e0 e2 e1 e3 */
+    return V16_DPP(u, 0, 2, 2, 0) + __mul24(V16_DPP(u, 3, 1, 1, 3), c.i_s);
+}
+template <class V> DEV V v16_fwd4x4_c(const V16C &c, const V &d)
+{
+    V r;
+    r.v = v16_fwd_quad_c(c, __builtin_amdgcn_ds_bpermute(c.xp, v16_fwd_quad_c(c, d.v)));
+    return r;
+}
+template <class V> DEV V v16_inv4x4_c(const V16C &c, const V &q)
+{
+    const int f = (int16_t)v16_inv_quad_c(c, __builtin_amdgcn_ds_bpermute(c.xp, q.v));             /* int16 between the passes, H:2436-2489 */
+    const int g = v16_inv_quad_c(c, __builtin_amdgcn_ds_bpermute(c.xp, f));
+    V r;
+    r.v = (int16_t)((g + 32) >> 6);
+    return r;
+}
+#undef V16_DPP
 /* bits 16t .. 16t+15 of the ballot belong to tile t */
 DEV unsigned long long v16_nonzero_ballot(const V16 &a) { return __ballot(a.v != 0); }
 DEV unsigned v16_nonzero_mask(const V16 &a) { return (unsigned)(__ballot(a.v != 0) & 0xffffu); }
@@ -349,6 +465,8 @@ DEV uint32_t alignbyte32(uint32_t hi, uint32_t lo, unsigned sh) { return __built
 DEV uint32_t ld32_aligned(const LDS_AS uint32_t *q) { return *q; }
 /* keeps the compiler from looking through a value (enc_kernels.h shr_opaque: the v_ashr_pk_u8_i32 finding) */
 DEV int opaque_int(int v) { asm volatile("" : "+v"(v)); return v; }
+/* low 32 bits of the product of two values of at most 24 bits: v_mul_i32_i24, full rate (a 32-bit v_mul_lo / v_mad_u64 runs at a quarter) */
+DEV int mul24(int a, int b) { return __mul24(a, b); }
 DEV int popc32(uint32_t v) { return __popc(v); }
 /* a progress counter of another workgroup, read past the caches' stale copies (relaxed, agent scope: an sc1 load) */
 DEV int dep_poll(const GLOBAL_AS int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -371,6 +489,18 @@ DEV V64 v64_quad_sum(const V64 &a)
 }
 DEV int v64_read(const V64 &a, int lane) { return __builtin_amdgcn_readlane(a.v, lane); }
 DEV int v64_own(const V64 &a, int) { return a.v; }                     /* inside a lane section: this lane's own value */
+template <class F> DEV void v64_each3(const V64 &a, const V64 &b, const V64 &c, F f) { f(LANE, a.v, b.v, c.v); }
+/* the value of the lane below / above inside the 16-lane row (DPP row_shr:1 / row_shl:1); the row's first / last lane keeps its own */
+DEV V64 v64_row_shr1(const V64 &a) { V64 r; r.v = __builtin_amdgcn_update_dpp(a.v, a.v, 0x111, 0xf, 0xf, false); return r; }
+DEV V64 v64_row_shl1(const V64 &a) { V64 r; r.v = __builtin_amdgcn_update_dpp(a.v, a.v, 0x101, 0xf, 0xf, false); return r; }
+/* minimum over the four quads of the 16-lane row, position by position inside the quad (DPP row_ror:4, row_ror:8) */
+DEV V64 v64_row_quadmin(const V64 &a)
+{
+    V64 r;
+    r.v = imin_raw(a.v, __builtin_amdgcn_update_dpp(a.v, a.v, 0x124, 0xf, 0xf, false));
+    r.v = imin_raw(r.v, __builtin_amdgcn_update_dpp(r.v, r.v, 0x128, 0xf, 0xf, false));
+    return r;
+}
 DEV uint64_t v64_nonzero_ballot(const V64 &a) { return __ballot(a.v != 0); }
 #endif
 

@@ -203,7 +203,7 @@ int  H264E_clip_restart(H264E_clip_t *clip, int frame, const int32_t state[2]);
  * 0..3 inter partitioning, 5 I4x4, 6 I16x16; uint8 used-cluster-candidates; 2 pad bytes} -- a per-macroblock trace for debugging */
 int  H264E_clip_read_records(H264E_clip_t *clip, int frame, void *dst /* macroblocks x 8 bytes */);
 void H264E_clip_close(H264E_clip_t *clip);
-/* diagnostic: per-phase cycle sums [32] of a -DH264E_STAMPS kernel build since the last call (zeros in the product) */
+/* diagnostic: per-phase sums [48] of a -DH264E_STAMPS kernel build since the last call (zeros in the product): [0..31] the rows' phases in cycles, [32..47] the finalizers' in 10 ns ticks */
 int  H264E_clip_stamps(H264E_clip_t *clip, unsigned long long *dst);
 
 #ifdef __cplusplus

@@ -29,7 +29,7 @@ def main():
     L = ce.L
     # the pool is private to the clip encoder: reach it through the stamp reader exported by the library
     L.H264E_clip_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
-    t = (C.c_ulonglong * 32)()
+    t = (C.c_ulonglong * 48)()
     L.H264E_clip_stamps(ce.c, t)
     nmb = sum(t[20:23])
     tot = sum(t[i] for i in ORDER)
@@ -47,6 +47,10 @@ def main():
               (t[24] / nmb, t[25] / nmb, t[26] / nmb, t[27] / nmb))
     if t[30]:
         print("mb_write: luma transform + quantiser + reconstruction %.0f cycles/MB (of the mb_write line above; the CAVLC of the residual blocks measured 2.3 k)" % (t[30] / nmb))
+    if t[37]:
+        nf = t[37]
+        print("finalizer workgroups (%d frames), microseconds per frame: wait for the frame's rows %.1f | wait for the verdict of the frame in front %.1f | exact walk of the records %.1f | slice splice %.1f | NAL escaping + export %.1f" %
+              (nf, t[32] / nf / 100.0, t[33] / nf / 100.0, t[34] / nf / 100.0, t[35] / nf / 100.0, t[36] / nf / 100.0))
     if t[29]:
         print("effective shader clock over the rows' lifetimes: %.0f MHz (cycle counter / 100 MHz wall clock)" % (100.0 * t[28] / t[29]))
 
