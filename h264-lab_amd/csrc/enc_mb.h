@@ -232,98 +232,97 @@ DEV int diamond_g(RowLds &L, const MbBuf &B, const MbCtx &m, int px, int py, mv3
 {
     const RefView &R = m.rv;
     const uint8_t *b = B.inp + 16*py + px;
-    /* the reference's uint16 cache[8]: four 16-bit fields each in `cur` (neighbours of the centre) and `prv` */
-    uint64_t cur, prv;
-#define CGET(c, d) ((uint32_t)((c) >> (16*(d))) & 0xffffu)
-#define CSET(c, d, v) c = ((c) & ~(0xffffull << (16*(d)))) | ((uint64_t)((v) & 0xffffu) << (16*(d)))
+    /* the reference's uint16 cache[8] (H:4993-4997): the SADs of the centre's four neighbours (c0..c3: +x, -x, +y, -y) and of the previous
+     * centre's (p0..p3), 0xffff = not evaluated -- the truncation to 16 bits and the sentinel are observable */
+    int c0, c1, c2, c3, p0, p1, p2, p3;
 #define DX(d) ((d) == 0 ? 4 : (d) == 1 ? -4 : 0)
 #define DY(d) ((d) == 2 ? 4 : (d) == 3 ? -4 : 0)
-    int dir, cloop, dir_prev, cost;
+#define SEL4(d, a0, a1, a2, a3) ((d) == 0 ? (a0) : (d) == 1 ? (a1) : (d) == 2 ? (a2) : (a3))
+    int cost;
     mv32 v;
     const int g = w >> 2, npass = (g*h) >> 4;
     for (;;)
     {
-        dir = 0; cloop = 4; dir_prev = -1;
-        cur = prv = ~0ull;
-        /* SADs of the centre's four neighbours are taken in one batch (one pass of the group's lanes, two packed reductions) the
-         * first time the reference's sequential scan asks for one of them; the scan itself is unchanged */
-        int have = 0, bs[4] = { 0, 0, 0, 0 };
-        do
+        /* H:4999-5051, one CENTRE per iteration instead of one direction: the reference scans the four neighbours of the centre in the order
+         * d0, d0+1, d0+2, d0+3 (d0 = the direction it arrived from; 0 at the start), skips those outside the range or already in the cache,
+         * caches every cost it takes and moves to the FIRST neighbour that improves on the centre.  With the four SADs taken in one batch that
+         * is a priority pick: the improving neighbour with the smallest scan position wins, the neighbours scanned up to it enter the cache. */
+        int d0 = 0, dir_prev = -1;
+        c0 = c1 = c2 = c3 = p0 = p1 = p2 = p3 = 0xffff;
+        for (;;)
         {
-            v = mvadd(mv, mvmk(DX(dir), DY(dir)));
-            if (in_rect(v, range) && CGET(cur, dir) == 0xffffu)
+            const int e0 = in_rect(mvadd(mv, mvmk(4, 0)), range) && c0 == 0xffff, e1 = in_rect(mvadd(mv, mvmk(-4, 0)), range) && c1 == 0xffff;
+            const int e2 = in_rect(mvadd(mv, mvmk(0, 4)), range) && c2 == 0xffff, e3 = in_rect(mvadd(mv, mvmk(0, -4)), range) && c3 == 0xffff;
+            if (!(e0 | e1 | e2 | e3)) break;
+            const int want = e0 | (e1 << 1) | (e2 << 2) | (e3 << 3);
+            int s4[4];
+            const int cx = px + (mvx(mv) >> 2), cy = py + (mvy(mv) >> 2);
+            if (rv_inside(R, cx - 1, cy - 1, cx + w, cy + h))
             {
-                if (!(have & (1 << dir)))
-                {
-                    int want = 0, s4[4];
-#pragma unroll
-                    for (int d = 0; d < 4; d++)
+                const lu8 *base = rv_ptr(R, cx, cy);
+                grp_sum4([&](int i, int *sv) {
+                    uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+                    for (int k = 0; k < npass; k++)
                     {
-                        const mv32 vd2 = mvadd(mv, mvmk(DX(d), DY(d)));
-                        if (in_rect(vd2, range) && CGET(cur, d) == 0xffffu) want |= 1 << d;
+                        const int d = i + 16*k, r = d >> (g >> 1), c4 = d & (g - 1);
+                        const uint32_t in4 = lds32(b + 16*r + 4*c4);
+                        const lu8 *p = base + r*WIN_STRIDE + 4*c4;
+                        /* all four neighbours lie inside the window: issue the loads together (one LDS wait instead of four);
+                         * sums of directions that are not wanted are simply not looked at */
+                        const uint32_t a0 = lds32u(p + 1), a1 = lds32u(p - 1), a2 = lds32u(p + WIN_STRIDE), a3 = lds32u(p - WIN_STRIDE);
+                        t0 = sad4_u8(a0, in4, t0); t1 = sad4_u8(a1, in4, t1); t2 = sad4_u8(a2, in4, t2); t3 = sad4_u8(a3, in4, t3);
                     }
-                    const int cx = px + (mvx(mv) >> 2), cy = py + (mvy(mv) >> 2);
-                    if (rv_inside(R, cx - 1, cy - 1, cx + w, cy + h))
+                    sv[0] = (int)t0; sv[1] = (int)t1; sv[2] = (int)t2; sv[3] = (int)t3;
+                }, s4);
+            } else
+            {
+                rv_wait_rect_g(R, cy - 1, cx + w, cy + h);
+                grp_sum4([&](int i, int *sv) {
+                    uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+                    for (int k = 0; k < npass; k++)
                     {
-                        const lu8 *base = rv_ptr(R, cx, cy);
-                        grp_sum4([&](int i, int *sv) {
-                            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-                            for (int k = 0; k < npass; k++)
-                            {
-                                const int d = i + 16*k, r = d >> (g >> 1), c4 = d & (g - 1);
-                                const uint32_t in4 = lds32(b + 16*r + 4*c4);
-                                const lu8 *p = base + r*WIN_STRIDE + 4*c4;
-                                /* all four neighbours lie inside the window: issue the loads together (one LDS wait instead of four);
-                                 * sums of directions that are not wanted are simply not looked at */
-                                const uint32_t a0 = lds32u(p + 1), a1 = lds32u(p - 1), a2 = lds32u(p + WIN_STRIDE), a3 = lds32u(p - WIN_STRIDE);
-                                t0 = sad4_u8(a0, in4, t0); t1 = sad4_u8(a1, in4, t1); t2 = sad4_u8(a2, in4, t2); t3 = sad4_u8(a3, in4, t3);
-                            }
-                            sv[0] = (int)t0; sv[1] = (int)t1; sv[2] = (int)t2; sv[3] = (int)t3;
-                        }, s4);
-                    } else
-                    {
-                        rv_wait_rect_g(R, cy - 1, cx + w, cy + h);
-                        grp_sum4([&](int i, int *sv) {
-                            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-                            for (int k = 0; k < npass; k++)
-                            {
-                                const int d = i + 16*k, r = d >> (g >> 1), c4 = d & (g - 1);
-                                const uint32_t in4 = lds32(b + 16*r + 4*c4);
-                                if (want & 1) t0 = sad4_u8(ref_load4(R.P, cx + 4*c4 + 1, cy + r), in4, t0);
-                                if (want & 2) t1 = sad4_u8(ref_load4(R.P, cx + 4*c4 - 1, cy + r), in4, t1);
-                                if (want & 4) t2 = sad4_u8(ref_load4(R.P, cx + 4*c4, cy + r + 1), in4, t2);
-                                if (want & 8) t3 = sad4_u8(ref_load4(R.P, cx + 4*c4, cy + r - 1), in4, t3);
-                            }
-                            sv[0] = (int)t0; sv[1] = (int)t1; sv[2] = (int)t2; sv[3] = (int)t3;
-                        }, s4);
+                        const int d = i + 16*k, r = d >> (g >> 1), c4 = d & (g - 1);
+                        const uint32_t in4 = lds32(b + 16*r + 4*c4);
+                        if (want & 1) t0 = sad4_u8(ref_load4(R.P, cx + 4*c4 + 1, cy + r), in4, t0);
+                        if (want & 2) t1 = sad4_u8(ref_load4(R.P, cx + 4*c4 - 1, cy + r), in4, t1);
+                        if (want & 4) t2 = sad4_u8(ref_load4(R.P, cx + 4*c4, cy + r + 1), in4, t2);
+                        if (want & 8) t3 = sad4_u8(ref_load4(R.P, cx + 4*c4, cy + r - 1), in4, t3);
                     }
-                    /* SAD + vector cost of the four neighbours */
-                    int c4v[4];
-                    grp_eval4([&](int d) -> int { return mv_cost(m, mvadd(mv, mvmk(DX(d), DY(d))), mv_pred); }, c4v);
-                    bs[0] = s4[0] + c4v[0]; bs[1] = s4[1] + c4v[1]; bs[2] = s4[2] + c4v[2]; bs[3] = s4[3] + c4v[3];
-                    have = want;
-                }
-                cost = dir == 0 ? bs[0] : dir == 1 ? bs[1] : dir == 2 ? bs[2] : bs[3];
-                CSET(cur, dir, (uint32_t)cost);
-                if (cost < min_sad)
-                {
-                    uint32_t corner = 0xffff;
-                    if (dir_prev >= 0) corner = CGET(prv, dir);
-                    prv = cur; cur = ~0ull;
-                    if (dir_prev >= 0) CSET(cur, dir_prev ^ 1, corner);
-                    CSET(cur, dir ^ 1, (uint32_t)min_sad);
-                    dir_prev = dir;
-                    dir--;
-                    cloop = 4 + 1;
-                    mv = v;
-                    min_sad = cost;
-                    have = 0;
-                }
+                    sv[0] = (int)t0; sv[1] = (int)t1; sv[2] = (int)t2; sv[3] = (int)t3;
+                }, s4);
             }
-            dir = (dir + 1) & 3;
-        } while (--cloop);
+            /* SAD + vector cost of the four neighbours */
+            int c4v[4];
+            grp_eval4([&](int d) -> int { return mv_cost(m, mvadd(mv, mvmk(DX(d), DY(d))), mv_pred); }, c4v);
+            const int b0 = s4[0] + c4v[0], b1 = s4[1] + c4v[1], b2 = s4[2] + c4v[2], b3 = s4[3] + c4v[3];
+            /* scan position of every direction, 4 = "does not improve"; the first improving one wins */
+            const int o0 = (0 - d0) & 3, o1 = (1 - d0) & 3, o2 = (2 - d0) & 3, o3 = (3 - d0) & 3;
+            const int wk = imin(imin((e0 && b0 < min_sad) ? o0 : 4, (e1 && b1 < min_sad) ? o1 : 4), imin((e2 && b2 < min_sad) ? o2 : 4, (e3 && b3 < min_sad) ? o3 : 4));
+            const int lim = wk < 4 ? wk : 3;
+            if (e0 && o0 <= lim) c0 = b0 & 0xffff;
+            if (e1 && o1 <= lim) c1 = b1 & 0xffff;
+            if (e2 && o2 <= lim) c2 = b2 & 0xffff;
+            if (e3 && o3 <= lim) c3 = b3 & 0xffff;
+            if (wk == 4) break;
+            {
+                /* H:5021-5040: move to the winner; the cache follows (the previous centre becomes the neighbour behind, and the
+                 * neighbour the last two moves enclose -- the "corner" -- is known from the centre before) */
+                const int win = (d0 + wk) & 3;
+                const int corner = dir_prev >= 0 ? SEL4(win, p0, p1, p2, p3) : 0xffff;
+                const int back = win ^ 1, side = dir_prev >= 0 ? (dir_prev ^ 1) : -1;
+                p0 = c0; p1 = c1; p2 = c2; p3 = c3;
+                c0 = back == 0 ? (min_sad & 0xffff) : side == 0 ? corner : 0xffff;
+                c1 = back == 1 ? (min_sad & 0xffff) : side == 1 ? corner : 0xffff;
+                c2 = back == 2 ? (min_sad & 0xffff) : side == 2 ? corner : 0xffff;
+                c3 = back == 3 ? (min_sad & 0xffff) : side == 3 ? corner : 0xffff;
+                min_sad = SEL4(win, b0, b1, b2, b3);
+                mv = mvadd(mv, mvmk(DX(win), DY(win)));
+                dir_prev = win;
+                d0 = win;
+            }
+        }
 
-        const int pri = CGET(cur, 3) >= CGET(cur, 2) ? 2 : 3, sec = CGET(cur, 1) >= CGET(cur, 0) ? 0 : 1;
+        const int pri = c3 >= c2 ? 2 : 3, sec = c1 >= c0 ? 0 : 1;
         v = mvadd(mv, mvmk(DX(pri) + DX(sec), DY(pri) + DY(sec)));
         if (in_rect(v, range))
         {
@@ -337,10 +336,8 @@ DEV int diamond_g(RowLds &L, const MbBuf &B, const MbCtx &m, int px, int py, mv3
         }
         break;
     }
-    const uint32_t c0 = CGET(cur, 0), c1 = CGET(cur, 1), c2 = CGET(cur, 2), c3 = CGET(cur, 3);
     STAMP(L, 25);
-#undef CGET
-#undef CSET
+#undef SEL4
 #undef DX
 #undef DY
 
