@@ -152,7 +152,10 @@ DEV uint32_t ref_load4(const Plane &P, int x, int y)
 DEV uint32_t lds32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 DEV void lds32_store(uint8_t *p, uint32_t v) { memcpy(p, &v, 4); }
 
-/* 4 bytes at an arbitrary LDS byte address: two aligned dword reads + v_alignbyte */
+/* 4 bytes at an arbitrary LDS byte address: two aligned dword reads + v_alignbyte.  (The MI355X also serves ONE unaligned ds_read_b32 --
+ * tests/gpu_repro/lds_unaligned.hip proves it for every alignment and width -- and that form was measured in round 4: bit-exact, 1.5 % faster
+ * for a lone frame, 5-6 % SLOWER with the chip full (8 slices 29.2 -> 27.4 M MB/s): an unaligned read costs the LDS two passes, and with
+ * sixteen waves per CU the LDS pipe is a shared bottleneck while the v_alignbyte goes to a vector unit with slack.  Not kept.) */
 DEV uint32_t lds32u(const lu8 *p)
 {
     const unsigned a = (unsigned)(uintptr_t)p & 3;
@@ -496,38 +499,66 @@ DEV int shr_opaque(int v, int s)
 {
     return opaque_int(v >> s);
 }
-DEV hp4_t halfpel3_win(const lu8 *at, int ox, int oy)
+/* One window row for the half-sample filters: the twelve samples at q - 4 .. q + 7 from FOUR aligned dwords (a lane's three overlapping
+ * unaligned dwords are six aligned reads otherwise: a third fewer LDS bytes, and the LDS pipe is the shared resource of a full chip) */
+DEV void hp_row_load(const lu8 *q, uint32_t &a, uint32_t &b, uint32_t &c)
 {
-    int th[6][4], cx[6][4];
+    const unsigned sh = (unsigned)(uintptr_t)q & 3;
+    const LDS_AS uint32_t *w = (const LDS_AS uint32_t *)(q - 4 - sh);
+    const uint32_t d0 = ld32_aligned(w), d1 = ld32_aligned(w + 1), d2 = ld32_aligned(w + 2), d3 = ld32_aligned(w + 3);
+    a = alignbyte32(d1, d0, sh); b = alignbyte32(d2, d1, sh); c = alignbyte32(d3, d2, sh);
+}
+
+/*
+ * The same three half-sample planes for `nrows` (1, 2 or 4) CONSECUTIVE rows of one 4-sample column group: row k needs the horizontal
+ * filters of window rows k-2 .. k+3, so consecutive rows share five of their six -- nrows + 5 filtered rows instead of 6 * nrows (a lane
+ * of the sub-pel search owns consecutive rows for exactly this reason: 9 instead of 24 for a 16x16 partition).  The filtered rows
+ * rotate through six register sets (everything is unrolled: the indices are compile-time); emit(k, planes) is called for row k.
+ * at = window pointer at integer sample (ix, iy) of row 0 = the top-left of the 2x2 integer cell that contains the three positions;
+ * (ox, oy) in {0,1}^2 = offset of the full-pel position inside that cell.  emit gets {full-pel samples, horizontal half sample on the row,
+ * vertical half sample in the column, centre half sample}, 4 samples each: same arithmetic as interp_core for (2,0), (0,2) and (2,2).
+ */
+template <class EMIT> DEV void halfpel3_rows(const lu8 *at, int ox, int oy, int nrows, EMIT emit)
+{
+    int th[6][4];
+    uint32_t cx[6];
 #pragma unroll
-    for (int r = 0; r < 6; r++)
+    for (int j = 0; j < 9; j++)
     {
-        const lu8 *q = at + (r - 2)*WIN_STRIDE;
-        const uint32_t a = lds32u(q - 4), b = lds32u(q), c = lds32u(q + 4);
-        int p[12];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { p[k] = (int)((a >> (8*k)) & 255); p[4 + k] = (int)((b >> (8*k)) & 255); p[8 + k] = (int)((c >> (8*k)) & 255); }
-#pragma unroll
-        for (int i = 0; i < 4; i++)
+        if (j < nrows + 5)
         {
-            th[r][i] = tap6(p[i + 2], p[i + 3], p[i + 4], p[i + 5], p[i + 6], p[i + 7]);
-            cx[r][i] = ox ? p[5 + i] : p[4 + i];
+            const int s = j % 6;
+            uint32_t a, b, c;
+            hp_row_load(at + (j - 2)*WIN_STRIDE, a, b, c);
+            int p[12];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { p[k] = (int)((a >> (8*k)) & 255); p[4 + k] = (int)((b >> (8*k)) & 255); p[8 + k] = (int)((c >> (8*k)) & 255); }
+#pragma unroll
+            for (int i = 0; i < 4; i++) th[s][i] = tap6(p[i + 2], p[i + 3], p[i + 4], p[i + 5], p[i + 6], p[i + 7]);
+            cx[s] = ox ? alignbyte32(c, b, 1) : b;                 /* the integer columns the vertical filter runs on */
+            if (j >= 5)
+            {
+                /* rows j-5 .. j are in the sets: output row j - 5 */
+                const int r0 = (j - 5) % 6, r1 = (j - 4) % 6, r2 = (j - 3) % 6, r3 = (j - 2) % 6, r4 = (j - 1) % 6, r5 = j % 6;
+                hp4_t o;
+                o.x = oy ? cx[r3] : cx[r2];
+                o.y = o.z = o.w = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                {
+#define CXB(r) ((int)((cx[r] >> (8*i)) & 255))
+                    /* shr_opaque: keeps the compiler from fusing "shift, clamp, pack" of two results into v_ashr_pk_u8_i32, whose
+                     * results did not match the separate instructions on gfx950 (ROCm 7.2) in this function (tests/gpu_repro/ashr_pk.hip) */
+                    const int fh = clip255(shr_opaque((oy ? th[r3][i] : th[r2][i]) + 16, 5));
+                    const int fv = clip255(shr_opaque(tap6(CXB(r0), CXB(r1), CXB(r2), CXB(r3), CXB(r4), CXB(r5)) + 16, 5));
+                    const int fd = clip255(shr_opaque(tap6(th[r0][i], th[r1][i], th[r2][i], th[r3][i], th[r4][i], th[r5][i]) + 512, 10));
+#undef CXB
+                    o.y |= (uint32_t)fh << (8*i); o.z |= (uint32_t)fv << (8*i); o.w |= (uint32_t)fd << (8*i);
+                }
+                emit(j - 5, o);
+            }
         }
     }
-    hp4_t o;
-    o.x = o.y = o.z = o.w = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-    {
-        const int f0 = oy ? cx[3][i] : cx[2][i];
-        /* shr_opaque: keeps the compiler from fusing "shift, clamp, pack" of two results into v_ashr_pk_u8_i32, whose
-         * results did not match the separate instructions on gfx950 (ROCm 7.2) in this function */
-        const int fh = clip255(shr_opaque((oy ? th[3][i] : th[2][i]) + 16, 5));
-        const int fv = clip255(shr_opaque(tap6(cx[0][i], cx[1][i], cx[2][i], cx[3][i], cx[4][i], cx[5][i]) + 16, 5));
-        const int fd = clip255(shr_opaque(tap6(th[0][i], th[1][i], th[2][i], th[3][i], th[4][i], th[5][i]) + 512, 10));
-        o.x |= (uint32_t)f0 << (8*i); o.y |= (uint32_t)fh << (8*i); o.z |= (uint32_t)fv << (8*i); o.w |= (uint32_t)fd << (8*i);
-    }
-    return o;
 }
 
 /* 4 interpolated samples at integer position (x,y); `inside` (wave-uniform) says the block's footprint is in the window */

@@ -373,29 +373,34 @@ DEV int diamond_g(RowLds &L, const MbBuf &B, const MbCtx &m, int px, int py, mv3
 #define AVG4(x, y) (((x) | (y)) - ((((x) ^ (y)) >> 1) & 0x7f7f7f7fu))                    /* per-byte (x + y + 1) >> 1 */
         grp_sum8([&](int i, int *sv) {
             uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
-            for (int k = 0; k < npass; k++)
-            {
-                const int d = i + 16*k, r = d >> (g >> 1), c4 = d & (g - 1), o = w*r + 4*c4;
+            /* a lane owns `npass` CONSECUTIVE rows of one 4-sample column group (not every 16th dword as elsewhere): consecutive rows share
+             * five of the six filtered window rows the half-sample planes need (enc_kernels.h halfpel3_rows) */
+            const int c4 = i & (g - 1), r0 = (i >> (g >> 1))*npass;
+            const auto probe = [&](int r, uint32_t q00, uint32_t q02, uint32_t q20, uint32_t q22) {
+                const int o = w*r + 4*c4;
                 const uint32_t in4 = lds32(b + 16*r + 4*c4);
-#define IP(vv) interp_luma4(R, false, px + (mvx(vv) >> 2) + 4*c4, py + (mvy(vv) >> 2) + r, mvx(vv) & 3, mvy(vv) & 3)
-                uint32_t q00, q02, q20, q22;
-                if (inside)
-                {
-                    /* all three half-sample planes from one pass over the window (halfpel3_win) */
-                    const hp4_t hp = halfpel3_win(rv_ptr(R, fx0 + 4*c4 - hp_ox, fy0 + r - hp_oy), hp_ox, hp_oy);
-                    q00 = hp.x; q22 = hp.w;
-                    q02 = hp_pq_vertical ? hp.z : hp.y;
-                    q20 = hp_pq_vertical ? hp.y : hp.z;
-                } else
-                {
-                    q00 = IP(mv); q02 = IP(v02); q20 = IP(v20); q22 = IP(v22);
-                }
-#undef IP
                 const uint32_t q01 = AVG4(q00, q02), q10 = AVG4(q00, q20), q11 = AVG4(q02, q20), q12 = AVG4(q22, q02);
                 lds32_store(scr + o, q00); lds32_store(scr + plane + o, q02); lds32_store(scr + 2*plane + o, q20); lds32_store(scr + 3*plane + o, q22);
                 t0 = sad4_u8(q02, in4, t0); t1 = sad4_u8(q01, in4, t1); t2 = sad4_u8(q20, in4, t2);
                 t3 = sad4_u8(q10, in4, t3); t4 = sad4_u8(q11, in4, t4); t5 = sad4_u8(q22, in4, t5);
                 t6 = sad4_u8(q12, in4, t6);
+            };
+            if (inside)
+            {
+                /* all three half-sample planes from one pass over the window */
+                halfpel3_rows(rv_ptr(R, fx0 + 4*c4 - hp_ox, fy0 + r0 - hp_oy), hp_ox, hp_oy, npass, [&](int k, const hp4_t &hp) {
+                    probe(r0 + k, hp.x, hp_pq_vertical ? hp.z : hp.y, hp_pq_vertical ? hp.y : hp.z, hp.w);
+                });
+            } else
+            {
+                for (int k = 0; k < npass; k++)
+                {
+                    const int r = r0 + k;
+#define IP(vv) interp_luma4(R, false, px + (mvx(vv) >> 2) + 4*c4, py + (mvy(vv) >> 2) + r, mvx(vv) & 3, mvy(vv) & 3)
+                    const uint32_t q00 = IP(mv), q02 = IP(v02), q20 = IP(v20), q22 = IP(v22);
+#undef IP
+                    probe(r, q00, q02, q20, q22);
+                }
             }
             sv[0] = (int)t0; sv[1] = (int)t1; sv[2] = (int)t2; sv[3] = (int)t3; sv[4] = (int)t4; sv[5] = (int)t5; sv[6] = (int)t6;
         }, s8);
