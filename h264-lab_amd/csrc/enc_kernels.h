@@ -737,28 +737,40 @@ DEV void wave_pred_chroma(uint8_t *dst, const uint8_t *left, const uint8_t *top,
  * four samples by the offsets of tables.h k_i4_sel, takes its SAD, the four row SADs of a mode are added inside the quad, and the
  * minimum over the modes -- cost << 4 | slot, so that the earliest slot wins ties exactly like the reference's strict "<" in its test
  * order DC,V,DDL,VL,H,HU,DDR,HD,VR -- is two DPP row rotations and three lane reads.
- * blk = the block's top-left sample in the LDS working picture (row stride bstride; row -1 / column -1 hold the neighbours);
+ * blk = the block's top-left sample in the LDS working picture (row stride as given to i4_lanes_make; row -1 / column -1 hold the neighbours);
  * in = input block (stride 16), pred = LDS output (stride 16); returns mode | cost << 4.
  */
 struct I4Scratch { alignas(4) uint8_t pool[48]; };      /* E at 0..13, F3 at 16..28, F2 at 32..43, (DC at 47 in k_i4_sel: taken from a register) */
 
 DEV int i4_slot_mode(int k) { return k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 3 : k == 3 ? 7 : k == 4 ? 1 : k == 5 ? 8 : k == 6 ? 4 : k == 7 ? 6 : 5; }
-/* lane 4k + y -> the four pool offsets of mode slot k, row y; never change: fetched once per macroblock */
-DEV V64 i4_sel_lanes()
+/* What never changes from block to block, one value per lane, fetched once per macroblock:
+ *   sel   lane 4k + y: the four pool offsets of mode slot k, row y (k_i4_sel);
+ *   info  lane 4k + y: mode number | neighbours the mode needs << 4 (H:1834-1960: DC none, V DDL VL the top, H HU the left, the rest all
+ *         three) | (k < 9) << 8;
+ *   eoff  lane k < 14: where border sample E[k] lies relative to the block's top-left sample in the working picture (low half), and where
+ *         it comes from when there is no top-right block (high half: its four samples repeat top[3]); E[13] = E[12] */
+struct I4Lanes { V64 sel, info, eoff; };
+DEV I4Lanes i4_lanes_make(int bstride)
 {
-    return v64_make([&](int l) -> int { const int k = l >> 2; return k < 9 ? (int)k_i4_sel[i4_slot_mode(k)][l & 3] : 0; });
-}
-DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_t *blk, int bstride, int mpred, int penalty, I4Scratch &S, const V64 &sel)
-{
-    /* border samples E[0..13] in lanes 0..13 (E[13] = E[12]); without a top-right block its four samples repeat top[3] */
-    const V64 e = v64_make([&](int l) -> int {
-        if (l > 13) return 0;
-        const int k = l > 12 ? 12 : l;
-        if (k < 4) return (int)blk[(3 - k)*bstride - 1];
-        if (k == 4) return (int)blk[-bstride - 1];
-        const int t = k - 5;
-        return (int)blk[-bstride + ((t > 3 && !(avail & AV_TR)) ? 3 : t)];
+    I4Lanes t;
+    t.sel = v64_make([&](int l) -> int { const int k = l >> 2; return k < 9 ? (int)k_i4_sel[i4_slot_mode(k)][l & 3] : 0; });
+    t.info = v64_make([&](int l) -> int {
+        const int k = l >> 2, need = k == 0 ? 0 : k <= 3 ? AV_T : k <= 5 ? AV_L : (AV_T | AV_L | AV_TL);
+        return k < 9 ? (i4_slot_mode(k) | (need << 4) | 0x100) : 0;
     });
+    t.eoff = v64_make([&](int l) -> int {
+        const int k = l > 12 ? 12 : l;
+        const int o = k < 4 ? (3 - k)*bstride - 1 : k == 4 ? -bstride - 1 : -bstride + (k - 5);
+        const int o2 = k > 8 ? -bstride + 3 : o;
+        return (int)(((uint32_t)o & 0xffffu) | ((uint32_t)o2 << 16));
+    });
+    return t;
+}
+DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_t *blk, int mpred, int penalty, I4Scratch &S, const I4Lanes &T)
+{
+    /* border samples E[0..13] in lanes 0..13 (the lanes behind them read E[12] again: no branch) */
+    const int tr = (avail & AV_TR) != 0;
+    const V64 e = v64_map(T.eoff, [&](int, int o) -> int { return (int)blk[tr ? (int)(int16_t)(o & 0xffff) : (o >> 16)]; });
     const V64 em = v64_row_shr1(e), ep = v64_row_shl1(e);        /* E[k-1] (E[0] itself for k = 0), E[k+1] */
     v64_each3(e, em, ep, [&](int l, int c, int a, int b) {
         if (l < 13) { S.pool[l] = (uint8_t)c; S.pool[16 + l] = (uint8_t)((a + 2*c + b + 2) >> 2); S.pool[32 + l] = (uint8_t)((c + b + 1) >> 1); }
@@ -773,21 +785,18 @@ DEV int wave_i4_choose(const uint8_t *in, uint8_t *pred, int avail, const uint8_
         dc = (hl && ht) ? (sl + st + 4) >> 3 : hl ? (sl + 2) >> 2 : ht ? (st + 2) >> 2 : 128;
     }
     wave_sync();
-    const V64 row = v64_map(sel, [&](int l, int o) -> int {
-        const int k = l >> 2;
-        if (k >= 9) return 0;
-        if (k == 0) return (int)((uint32_t)dc*0x01010101u);
+    /* every lane gathers (lanes that stand for no mode gather pool[0]: harmless, and no branch); the DC slot takes the mean */
+    const V64 row = v64_map(T.sel, [&](int l, int o) -> int {
         const uint32_t u = (uint32_t)o;
-        return (int)((uint32_t)S.pool[u & 255] | ((uint32_t)S.pool[(u >> 8) & 255] << 8) | ((uint32_t)S.pool[(u >> 16) & 255] << 16) | ((uint32_t)S.pool[u >> 24] << 24));
+        const uint32_t g = (uint32_t)S.pool[u & 255] | ((uint32_t)S.pool[(u >> 8) & 255] << 8) | ((uint32_t)S.pool[(u >> 16) & 255] << 16) | ((uint32_t)S.pool[u >> 24] << 24);
+        return (int)((l >> 2) == 0 ? (uint32_t)dc*0x01010101u : g);
     });
-    const V64 qs = v64_quad_sum(v64_map(row, [&](int l, int r) -> int { return (l >> 2) < 9 ? (int)sad4_u8(lds32(in + 16*(l & 3)), (uint32_t)r, 0) : 0; }));
-    /* cost << 4 | slot; a mode whose neighbours are missing cannot win (H:1834-1960: DC always, V DDL VL need the top, H HU the left, the rest all three) */
+    const V64 qs = v64_quad_sum(v64_map(row, [&](int l, int r) -> int { return (int)sad4_u8(lds32(in + 16*(l & 3)), (uint32_t)r, 0); }));
+    /* cost << 4 | slot; a mode whose neighbours are missing cannot win */
     const V64 key = v64_map(qs, [&](int l, int sad) -> int {
-        const int k = l >> 2;
-        if (k >= 9) return 0x7fffffff;
-        const int need = k == 0 ? 0 : k <= 3 ? AV_T : k <= 5 ? AV_L : (AV_T | AV_L | AV_TL);
-        if ((avail & need) != need) return 0x7fffffff;
-        return ((sad + (i4_slot_mode(k) != mpred ? penalty : 0)) << 4) | k;
+        const int f = v64_own(T.info, l), need = (f >> 4) & 15;
+        const int ok = (f & 0x100) && (avail & need) == need;
+        return ok ? (((sad + ((f & 15) != mpred ? penalty : 0)) << 4) | (l >> 2)) : 0x7fffffff;
     });
     const V64 rm = v64_row_quadmin(key);
     const int bk = imin(imin(v64_read(rm, 0), v64_read(rm, 16)), v64_read(rm, 32));

@@ -736,7 +736,7 @@ template <class BOUND> DEV int intra4_choose(RowLds &L, MbBuf &B, const MbCtx &m
     int cost = m.lambda_i4;
     unsigned nz_mask = 0;
     if (cost >= bound()) return I4_LOST;
-    const V64 sel = i4_sel_lanes();                                                 /* every lane's own prediction-table entry, for all 16 blocks */
+    const I4Lanes T = i4_lanes_make(24);                                            /* every lane's own table entries, for all 16 blocks */
     const I4Q K = i4q_make(L.qdat[0]);                                              /* ... and its quantiser / transform constants */
     WAVE_FOR(l)
     {
@@ -759,7 +759,7 @@ template <class BOUND> DEV int intra4_choose(RowLds &L, MbBuf &B, const MbCtx &m
         int mpred = imin(L.i4_left[r], B.i4_top[c]);
         if (mpred < 0) mpred = 2;
         STAMP(L, 19);
-        int res = wave_i4_choose(bin, pr, a, blk, 24, mpred, MUL_LAMBDA(3, m.lambda_q4), L.i4s, sel);
+        int res = wave_i4_choose(bin, pr, a, blk, mpred, MUL_LAMBDA(3, m.lambda_q4), L.i4s, T);
         STAMP(L, 31);
         const int mode = res & 15, sad = res >> 4;
         L.i4_left[r] = B.i4_top[c] = (int8_t)mode;

@@ -131,7 +131,7 @@ DEV void stage_selftest(StageLds &S, RowLds &L, int stage, const GLOBAL_AS uint8
             if (l < 16) lds32_store(S.o + 4*l, 0u);
         }
         wave_sync();
-        const int res = wave_i4_choose(S.a, S.o, a[0], S.nb + 24 + 4, 24, a[1], a[2], S.i4s, i4_sel_lanes());
+        const int res = wave_i4_choose(S.a, S.o, a[0], S.nb + 24 + 4, a[1], a[2], S.i4s, i4_lanes_make(24));
         wave_sync();
         WAVE_FOR(l) { if (l < 16) gstore32((gu8 *)out + 8 + 4*l, lds32(S.o + 4*l)); }
         if (wave_lane() == 0) { oi[0] = res & 15; oi[1] = res >> 4; }
