@@ -353,6 +353,41 @@ DEV int grp_sad_ref(const RefView &R, int x0, int y0, const uint8_t *b, int w, i
     });
 }
 
+/* the same 16x16 SAD with its 8x8 quadrant sums for a lane group (wave.h): four groups take four candidate positions at once */
+DEV int grp_sad_ref_q(const RefView &R, int x0, int y0, const uint8_t *b, int sad4[4])
+{
+    if (rv_inside(R, x0, y0, x0 + 15, y0 + 15))
+    {
+        const lu8 *base = rv_ptr(R, x0, y0);
+        grp_sum4([&](int i, int *v) {
+            uint32_t top = 0, bot = 0;
+            const int c = i & 3;
+            for (int k = 0; k < 4; k++)
+            {
+                const int r = (i >> 2) + 4*k;
+                const uint32_t s = sad4_u8(lds32u(base + r*WIN_STRIDE + 4*c), lds32(b + 16*r + 4*c), 0);
+                if (k < 2) top += s; else bot += s;
+            }
+            v[c >> 1] = (int)top; v[2 + (c >> 1)] = (int)bot;
+        }, sad4);
+    } else
+    {
+        rv_wait_rect_g(R, y0, x0 + 15, y0 + 15);
+        grp_sum4([&](int i, int *v) {
+            uint32_t top = 0, bot = 0;
+            const int c = i & 3;
+            for (int k = 0; k < 4; k++)
+            {
+                const int r = (i >> 2) + 4*k;
+                const uint32_t s = sad4_u8(ref_load4(R.P, x0 + 4*c, y0 + r), lds32(b + 16*r + 4*c), 0);
+                if (k < 2) top += s; else bot += s;
+            }
+            v[c >> 1] = (int)top; v[2 + (c >> 1)] = (int)bot;
+        }, sad4);
+    }
+    return sad4[0] + sad4[1] + sad4[2] + sad4[3];
+}
+
 /* 16x16 SAD with the four 8x8 quadrant sums (H:2178-2187) */
 DEV int wave_sad_ref_q(const RefView &R, int x0, int y0, const uint8_t *b, int sad4[4])
 {

@@ -407,11 +407,18 @@ DEV int diamond_g(RowLds &L, const MbBuf &B, const MbCtx &m, int px, int py, mv3
         wave_sync();
         int best = -1, c8[8];
         mv32 vbest = mv;
-        /* the seven vector costs */
-        grp_eval8([&](int j) -> int {
-            const mv32 vj = j == 0 ? v02 : j == 1 ? v01 : j == 2 ? v20 : j == 3 ? v10 : j == 4 ? v11 : j == 5 ? v22 : v12;
-            return mv_cost(m, vj, mv_pred);
-        }, c8);
+        /* the seven vector costs (H:4952-4956: lambda * (se bits of dx + se bits of dy) >> 4): the probes lie at 0, 1 and 2 steps of pq and of sq
+         * from mv, one of the two vertical and the other horizontal, so their cost is made of three code lengths per axis */
+        {
+            const int pax = hp_pq_vertical, p_step = pax ? mvy(pq) : mvx(pq), s_step = pax ? mvx(sq) : mvy(sq);
+            const int p_mv = pax ? mvy(mv) : mvx(mv), s_mv = pax ? mvx(mv) : mvy(mv), p_pr = pax ? mvy(mv_pred) : mvx(mv_pred), s_pr = pax ? mvx(mv_pred) : mvy(mv_pred);
+            int P[4], S[4];
+            grp_eval4([&](int k) -> int { return se_len((int16_t)(p_mv + k*p_step) - p_pr); }, P);
+            grp_eval4([&](int k) -> int { return se_len((int16_t)(s_mv + k*s_step) - s_pr); }, S);
+            c8[0] = MUL_LAMBDA(P[2] + S[0], m.lambda_mv); c8[1] = MUL_LAMBDA(P[1] + S[0], m.lambda_mv); c8[2] = MUL_LAMBDA(P[0] + S[2], m.lambda_mv);
+            c8[3] = MUL_LAMBDA(P[0] + S[1], m.lambda_mv); c8[4] = MUL_LAMBDA(P[1] + S[1], m.lambda_mv); c8[5] = MUL_LAMBDA(P[2] + S[2], m.lambda_mv);
+            c8[6] = MUL_LAMBDA(P[2] + S[1], m.lambda_mv);
+        }
 #define TRY(j, vv) { const int cst = s8[j] + c8[j]; if (cst < min_sad) { min_sad = cst; vbest = (vv); best = j; } }
         TRY(0, v02) TRY(1, v01) TRY(2, v20) TRY(3, v10) TRY(4, v11) TRY(5, v22) TRY(6, v12)
 #undef TRY
@@ -620,20 +627,42 @@ template <class SIG> DEV void inter_choose(RowLds &L, MbBuf &B, MbCtx &m, SIG si
     wave_sync();
 
     const rect_t lim = mv_limit(m);
-    for (; j < ncand; j++)
     {
-        const mv32 cj = cand.get(j), va = mb_abs(m, cj);
-        if (in_rect(va, lim))
+        /* H:5388-5409: the start candidates are compared in list order with a strict "<" on SAD + vector cost, every one that is tried also
+         * votes on the partition types to search (H:5224-5257).  Four candidates at a time, one per lane group: the winner is the smallest
+         * (SAD + cost) << 4 | list position (the earliest of equals, like the strict "<"), starting from the skip vector's figures when it
+         * is a full-sample vector (j = 1); the votes are OR-ed over all groups. */
+        int key = 0x7fffffff, h1 = 0, h2 = 0, h3 = 0;
+        for (int base = j; base < ncand; base += 4)
         {
-            int c = mv_cost(m, cj, mv_pred16), s4[4];
-            sad = wave_sad_ref_q(R, bx + (mvx(cj) >> 2), by + (mvy(cj) >> 2), B.inp, s4);
-            if (m.speed < 1) partition_hints(s4, prefer);
-            if (sad + c < sad_best + cand_cost_best)
+            GRP_EACH(gq)
             {
-                cand_cost_best = c;
-                sad_best = sad;
-                mv_best = cj;
+                const int jj = base + gq;
+                const mv32 cj = (mv32)cand.get_any(jj), va = mb_abs(m, cj);          /* (read with every lane active: a lane-crossing read) */
+                if (jj < ncand)
+                {
+                    if (in_rect(va, lim))
+                    {
+                        int s4[4], hint[4] = { 0, 0, 0, 0 };
+                        const int sad = grp_sad_ref_q(R, bx + (mvx(cj) >> 2), by + (mvy(cj) >> 2), B.inp, s4);
+                        if (m.speed < 1) partition_hints(s4, hint);
+                        h1 |= hint[1]; h2 |= hint[2]; h3 |= hint[3];
+                        key = imin(key, ((sad + mv_cost(m, cj, mv_pred16)) << 4) | jj);
+                    }
+                }
             }
+        }
+        /* gather: the groups' votes and the smallest key of the four groups (a group's lanes agree) */
+        prefer[1] |= wave_ballot([&](int) -> int { return h1; }) != 0;
+        prefer[2] |= wave_ballot([&](int) -> int { return h2; }) != 0;
+        prefer[3] |= wave_ballot([&](int) -> int { return h3; }) != 0;
+        const V64 kv = v64_make([&](int) -> int { return key; });
+        const int kmin = imin(imin(v64_read(kv, 0), v64_read(kv, 16)), imin(v64_read(kv, 32), v64_read(kv, 48)));
+        if (kmin != 0x7fffffff && (kmin >> 4) < sad_best + cand_cost_best)
+        {
+            mv_best = (mv32)cand.get(kmin & 15);
+            cand_cost_best = mv_cost(m, mv_best, mv_pred16);
+            sad_best = (kmin >> 4) - cand_cost_best;
         }
     }
     sad_best += mv_cost(m, mv_best, mv_pred16);

@@ -540,12 +540,14 @@ struct LaneArr
     int get(int i) const { return a[i]; }
     void set(int i, int v) { a[i] = v; }
     int has(int v, int n) const { for (int i = 0; i < n; i++) if (a[i] == v) return 1; return 0; }     /* is v among the first n elements? */
+    int get_any(int i) const { return a[i & 63]; }       /* inside a lane-group section: the index may differ from group to group */
 #else
     int r;
     __device__ __forceinline__ void clear() { r = 0; }
     __device__ __forceinline__ int get(int i) const { return __builtin_amdgcn_readlane(r, __builtin_amdgcn_readfirstlane(i)); }
     __device__ __forceinline__ void set(int i, int v) { r = (LANE == __builtin_amdgcn_readfirstlane(i)) ? __builtin_amdgcn_readfirstlane(v) : r; }    /* compare + select: no v_writelane builtin */
     __device__ __forceinline__ int has(int v, int n) const { return __ballot(LANE < n && r == __builtin_amdgcn_readfirstlane(v)) != 0; }
+    __device__ __forceinline__ int get_any(int i) const { return __builtin_amdgcn_ds_bpermute(4*(i & 63), r); }     /* per-lane index (lane groups) */
 #endif
 };
 
