@@ -1254,6 +1254,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
         const double t_submit = now_ms();
         double t_first = 0, t_last = 0;
         int rc_miss = 0, take = -1, moved_from = -1, moved_to = -1, relaunch = 0;
+        const char *why = "all frames delivered";       /* what ended the launch (H264E_DEBUG) */
         if (h264e_hip_submit(c->pool, tasks)) goto done;
 
         /* consume the frames in stream order while the launch is still running */
@@ -1279,6 +1280,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
                  * encoded in the next launch */
                 if (dn < 0) goto done;
                 if (h264e_hip_stream_abort(c->pool)) goto done;
+                why = "the hedge leaf with the exact QP did not complete (its own mv_clusters validation, or stopped)";
                 break;
             }
             if (dn == 2 && r1.walk_status == 2)
@@ -1291,6 +1293,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
                 c->first_dev = 1;
                 c->after[0] = r1.state_out[0]; c->after[1] = r1.state_out[1]; c->have_after = 1;
                 stats.reencoded_gops++;             /* counts relaunches */
+                why = "mv_clusters mis-speculation";
                 break;
             }
             if (dn != 1)
@@ -1383,6 +1386,7 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             {
                 if (h264e_hip_stream_abort(c->pool)) goto done;
                 stats.reencoded_gops++;
+                why = is_hedge ? "QP miss covered by a hedge leaf (nothing behind a leaf)" : "QP miss, no hedge leaf with the exact QP";
                 break;
             }
             if (take >= 0) i = F - 1;           /* the chain ends here: one more round, for the leaf */
@@ -1422,8 +1426,9 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             }
         } else if (c->narrow_ok && c->next >= c->wide_until) { c->narrow = 1; c->far_acc = 0; c->far_frames = 0; }
         if (getenv("H264E_DEBUG"))
-            fprintf(stderr, "clip launch %d (first row %d, %s window, %lld far reads): %d frames in flight, %d valid, next %d; first frame after %.2f ms, then %.3f ms/frame, drained %.2f ms after the last\n",
-                    stats.rounds, tasks[0].first_row, tasks[0].narrow_window ? "narrow" : "wide", far_reads, F, nvalid, c->next, t_first - t_submit, nvalid > 1 ? (t_last - t_first)/(nvalid - 1 + (nvalid < F)) : 0.0, now_ms() - t_last);
+            fprintf(stderr, "clip launch %d (first row %d, %s window, %lld far reads): %d frames in flight, %d valid, next %d; first frame after %.2f ms, then %.3f ms/frame, drained %.2f ms after the last; ended by: %s%s\n",
+                    stats.rounds, tasks[0].first_row, tasks[0].narrow_window ? "narrow" : "wide", far_reads, F, nvalid, c->next, t_first - t_submit, nvalid > 1 ? (t_last - t_first)/(nvalid - 1 + (nvalid < F)) : 0.0, now_ms() - t_last,
+                    full ? "output buffer full" : why, nh ? " (+ hedge leaves)" : "");
         if (full && c->next == first)
         {
             snprintf(g_host_err, sizeof(g_host_err), "output buffer too small for one frame");

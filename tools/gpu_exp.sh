@@ -1,6 +1,11 @@
 #!/bin/bash
-# one-off GPU visit (round 4): the full-length 4K goldens and the shard re-encode probe at 4K x 1200
+# one-off GPU visit: issue priorities (s_setprio by position in the launch) on / off
 cd ${GRAFT_REPO_ROOT:-.}
-mkdir -p gpurun_out/r4_4k
-timeout -k 10 500 python -m pytest "tests/test_gpu_golden_big.py::test_full_length_stream_matches_reference" -m gpu -x -q -k "4k_1200" > gpurun_out/r4_4k/tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r4_4k/tests.log
-H264E_QUIET=1 timeout -k 10 500 python tools/shard_probe.py 1200 3840 2160 30 1 8 > gpurun_out/r4_4k/shard_probe.txt 2>&1; echo "probe rc=$?"; cat gpurun_out/r4_4k/shard_probe.txt
+export H264E_QUIET=1
+for p in 0 1; do
+  echo "--- H264E_PRIO=$p"
+  for cfg in "600 1920 1080 30 26 0 0" "600 1920 1080 30 26 8 0" "60 1920 1080 30 26 0 4000" "60 1920 1080 30 26 8 4000" "240 3840 2160 30 26 0 0" "3000 352 288 30 26 0 0"; do H264E_PRIO=$p timeout -k 10 200 python tools/clip_debug.py $cfg 2>/dev/null | tail -1; done
+  H264E_PRIO=$p timeout -k 10 120 python tools/single_frame_latency.py
+done
+unset H264E_QUIET
+H264E_PRIO=1 timeout -k 10 200 python tools/clip_debug.py 600 1920 1080 30 26 0 0 2>&1 | tail -26 | cut -c1-200
