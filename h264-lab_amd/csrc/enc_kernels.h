@@ -80,12 +80,18 @@ struct BitW
 /* H:2688-2702: append n <= 32 bits.  Uniform: all lanes hold the same state and store the same word. */
 DEV void bw_put(BitW &b, int n, uint32_t v)
 {
+    /* whatever the caller read from LDS (vector differences, intra modes, skip runs) is wave-uniform but a vector register to the compiler,
+     * and ONE such operand makes the whole writer state a vector value for the rest of the macroblock: every later put -- the CAVLC
+     * codes included -- then runs on the vector unit with 64-bit shifts (a quarter-rate instruction) and exec-mask branches */
+    n = uni(n); v = (uint32_t)uni((int)v);
     b.acc = (b.acc << n) | (uint64_t)v;
     b.nacc += n;
     if (b.nacc >= 32)
     {
         b.nacc -= 32;
-        if (b.pos < b.cap) { if (wave_lane() == 0) cstore32((gu8 *)(b.buf + b.pos), (uint32_t)(b.acc >> b.nacc)); }     /* read by the finalizer workgroup */
+        /* every lane stores the same word to the same address (one memory request for the wave): a store under "lane 0 only" is a divergent
+         * branch in the middle of the writer, behind which the compiler keeps the writer's state in vector registers */
+        if (b.pos < b.cap) cstore32((gu8 *)(b.buf + b.pos), (uint32_t)(b.acc >> b.nacc));     /* read by the finalizer workgroup */
         else b.overflow = 1;
         b.pos++;
         b.acc &= (1ull << b.nacc) - 1;
@@ -431,6 +437,14 @@ DEV int wave_sad_lds_q(const uint8_t *a, const uint8_t *b, int sad4[4])
 /* ------------------------------------------------------------------ inter prediction */
 
 DEV int tap6(int a, int b, int c, int d, int e, int f) { return a - 5*b + 20*c + 20*d - 5*e + f; }
+/* the same filter on SECOND-stage operands (15-bit sums of the first stage): (a + f) + 5*(4*(c + d) - (b + e)) in shifts and adds -- the compiler
+ * cannot know that they fit 24 bits and would take 32-bit multiplies, which run at a quarter of the rate of an add on this machine (for byte
+ * operands it finds 24-bit multiply-adds with byte selects by itself: measured, the shift form is slower there) */
+DEV int tap6w(int a, int b, int c, int d, int e, int f)
+{
+    const int t = ((c + d) << 2) - (b + e);
+    return (a + f) + (t << 2) + t;
+}
 
 /*
  * Standard H.264 quarter-sample luma interpolation (H:2079-2131) of 4 adjacent samples, fraction (fx,fy): half
@@ -496,7 +510,7 @@ template <class LD> DEV uint32_t interp_core(LD ld, int fx, int fy)
         {
             const int hv = vd ? clip255((tap6(cb[0][i + 1], cb[1][i + 1], cb[2][i + 1], cb[3][i + 1], cb[4][i + 1], cb[5][i + 1]) + 16) >> 5)
                               : clip255((tap6(cb[0][i], cb[1][i], cb[2][i], cb[3][i], cb[4][i], cb[5][i]) + 16) >> 5);
-            const int hd = clip255((tap6(th[0][i], th[1][i], th[2][i], th[3][i], th[4][i], th[5][i]) + 512) >> 10);
+            const int hd = clip255((tap6w(th[0][i], th[1][i], th[2][i], th[3][i], th[4][i], th[5][i]) + 512) >> 10);
             const int hh = clip255(((fy == 3 ? th[3][i] : th[2][i]) + 16) >> 5);    /* b (row y) or s (row y+1) */
             if (fx == 2)      { A[i] = hd; B[i] = hh; }                        /* f j q */
             else if (fy == 2) { A[i] = hv; B[i] = hd; }                        /* i k */
@@ -586,7 +600,7 @@ template <class EMIT> DEV void halfpel3_rows(const lu8 *at, int ox, int oy, int 
                      * results did not match the separate instructions on gfx950 (ROCm 7.2) in this function (tests/gpu_repro/ashr_pk.hip) */
                     const int fh = clip255(shr_opaque((oy ? th[r3][i] : th[r2][i]) + 16, 5));
                     const int fv = clip255(shr_opaque(tap6(CXB(r0), CXB(r1), CXB(r2), CXB(r3), CXB(r4), CXB(r5)) + 16, 5));
-                    const int fd = clip255(shr_opaque(tap6(th[r0][i], th[r1][i], th[r2][i], th[r3][i], th[r4][i], th[r5][i]) + 512, 10));
+                    const int fd = clip255(shr_opaque(tap6w(th[r0][i], th[r1][i], th[r2][i], th[r3][i], th[r4][i], th[r5][i]) + 512, 10));
 #undef CXB
                     o.y |= (uint32_t)fh << (8*i); o.z |= (uint32_t)fv << (8*i); o.w |= (uint32_t)fd << (8*i);
                 }
@@ -966,7 +980,7 @@ DEV int quant_chroma_dc(qblk_t *q, int16_t *dc, int16_t *lev, const uint16_t *qd
     }
     for (int i = 0; i < 4; i++) q[i].dq[0] = (int16_t)(v[i]*deq);
     wave_sync();
-    return (v[0] | v[1] | v[2] | v[3]) != 0;
+    return uni((v[0] | v[1] | v[2] | v[3]) != 0);
 }
 
 /*

@@ -251,8 +251,10 @@ DEV int diamond_g(RowLds &L, const MbBuf &B, const MbCtx &m, int px, int py, mv3
         c0 = c1 = c2 = c3 = p0 = p1 = p2 = p3 = 0xffff;
         for (;;)
         {
-            const int e0 = in_rect(mvadd(mv, mvmk(4, 0)), range) && c0 == 0xffff, e1 = in_rect(mvadd(mv, mvmk(-4, 0)), range) && c1 == 0xffff;
-            const int e2 = in_rect(mvadd(mv, mvmk(0, 4)), range) && c2 == 0xffff, e3 = in_rect(mvadd(mv, mvmk(0, -4)), range) && c3 == 0xffff;
+            /* (the centre lies inside the range -- set_range clips the start vector into it, a move only goes to a neighbour inside it -- so a
+             * neighbour can leave it on its own side only: one comparison each instead of in_rect's four) */
+            const int e0 = mvx(mv) + 4 <= range.x1 && c0 == 0xffff, e1 = mvx(mv) - 4 >= range.x0 && c1 == 0xffff;
+            const int e2 = mvy(mv) + 4 <= range.y1 && c2 == 0xffff, e3 = mvy(mv) - 4 >= range.y0 && c3 == 0xffff;
             if (!(e0 | e1 | e2 | e3)) break;
             const int want = e0 | (e1 << 1) | (e2 << 2) | (e3 << 3);
             int s4[4];
@@ -929,7 +931,9 @@ DEV void mb_write(RowLds &L, MbBuf &B, MbCtx &m, BitW &b)
         }
         cbpc = imin(cbpc, 2);
         /* roll back to skip (H:4493-4499) */
-        if (!(m.type | cbpl | cbpc) && B.mv[0] == m.mv_skip_pred) m.type = -1;
+        /* (uni: what comes back from LDS is a vector value to the compiler; a branch on it would make everything the branch touches -- the
+         * bit writer's state first of all -- a vector value, and the whole syntax / CAVLC part would run on the vector unit) */
+        if (!(m.type | cbpl | cbpc) && (mv32)uni((int)B.mv[0]) == m.mv_skip_pred) m.type = -1;
     }
 
     if (m.type == -1)
@@ -959,7 +963,7 @@ DEV void mb_write(RowLds &L, MbBuf &B, MbCtx &m, BitW &b)
         if (mb_type >= 5 && m.slice_type == 2) mb_type -= 5;
         if (m.slice_type != 2)
         {
-            if (L.coded_any) bw_ue(b, (uint32_t)L.skip_run);
+            if (uni(L.coded_any)) bw_ue(b, (uint32_t)L.skip_run);
             else L.lead_skips = L.skip_run;             /* the finalizer writes this run: it may extend into earlier rows */
             L.skip_run = 0;
         }
@@ -971,7 +975,7 @@ DEV void mb_write(RowLds &L, MbBuf &B, MbCtx &m, BitW &b)
             if (m.type == 5)
                 for (int i = 0; i < 16; i++)
                 {
-                    int md = L.i4_mode[SCAN8(i)];
+                    const int md = uni((int)L.i4_mode[SCAN8(i)]);
                     if (md < 0) bw_put(b, 1, 1); else bw_put(b, 4, (uint32_t)md);
                 }
             int cm = m.i16_mode;

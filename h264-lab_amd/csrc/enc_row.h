@@ -313,7 +313,7 @@ template <int GEOM, class HOOK> DEV void mb_recon_front(RowLds &L, MbBuf &B, MbC
         GLOBAL_AS h264e_mbrec_t *rec = C.mbrec + (size_t)T.frame_slot*G.nmb + m.num;
         const uint32_t mv0 = m.type < 5 ? (uint32_t)B.mv[0] : 0u;
         const uint64_t w = (uint64_t)mv0 | ((uint64_t)(uint8_t)(int8_t)m.type << 32) | ((uint64_t)(m.used_cand & 255) << 40);
-        if (wave_lane() == 0) cstore64((gu8 *)rec, w);
+        cstore64((gu8 *)rec, w);                /* (every lane the same word: no divergent branch, see enc_kernels.h bw_put) */
     }
 
     /* keep the UNFILTERED right column / bottom row for intra prediction (h264-lab.h:4693-4714) */

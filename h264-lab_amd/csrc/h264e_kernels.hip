@@ -43,6 +43,11 @@ DEV int poll_progress(const GLOBAL_AS int *flag, int need, int &seen, unsigned s
     }
 }
 
+/* a progress counter of this row, for other workgroups (relaxed, agent scope; the payload in front of it was stored write-through and drained).
+ * Every lane stores the same value to the same word -- one memory request for the wave: a store under "lane 0 only" is a divergent
+ * branch, and behind one the compiler keeps the surrounding wave-uniform state (loop counters, the bit writer) in vector registers. */
+DEV void publish(GLOBAL_AS int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 /* ---- hand-off words of the two-wave pipeline (LDS): release / acquire at workgroup scope, polled with s_sleep */
 DEV int flag_get(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DEV void flag_set(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -387,7 +392,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
              * no agent-scope release (L2 write-back) needed */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            if (LANE == 0) __hip_atomic_store(my_progress, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            publish(my_progress, x + 1);
             STAMP(L, 14);
         }
         if (WAVES >= 2)
@@ -457,7 +462,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
             mb_recon_back<GEOM>(L, L.mb[x & 1], m, G, C, RT, row, x, row0, row1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            if (LANE == 0) __hip_atomic_store(my_progress, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            publish(my_progress, x + 1);
             flag_set(&L.f_wdone, x + 1);
         }
 #ifdef H264E_STAMPS
@@ -499,7 +504,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
                     const auto publish_decided = [&]() {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __builtin_amdgcn_wave_barrier();
-                        if (LANE == 0) __hip_atomic_store(my_decided, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        publish(my_decided, x + 1);
                     };
                     if (WAVES == 4)
                     {
@@ -526,7 +531,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
             if (WAVES == 4) { STAMP(L, 14); continue; }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            if (LANE == 0) __hip_atomic_store(my_progress, x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            publish(my_progress, x + 1);
             flag_set(&L.f_wdone, x + 1);
             STAMP(L, 14);
         }
