@@ -274,32 +274,49 @@ DEV void rv_wait_rect_g(const RefView &V, int y0, int x1, int y1)
     consumer_acquire();
 }
 
-/* one lane per window row: four 16-byte loads when the window's columns lie inside the picture (uniform test),
- * clamped dword loads at the picture's left/right border */
+/* The window from HBM: four lanes per window row, 16 bytes each -- one wave instruction reads sixteen rows as whole 64-byte segments (four
+ * instructions for the window; one lane per row and 8 bytes per load were seven instructions touching 52 different lines each) -- when the
+ * window's columns lie inside the picture (uniform test); clamped dword loads, one lane per row, at the picture's left / right border. */
 DEV void wave_load_window(uint8_t *win, const Plane &P, int wx0, int wy0, int narrow)
 {
-    /* narrow geometry (h264e_dev.h): only 53 columns x 52 rows of the window are ever read: 52 rows of 56 bytes are loaded */
-    const int rows = narrow ? H264E_NARROW_VH : WIN_W, nq = narrow ? (H264E_NARROW_VW + 7)/8 : WIN_W/8;
-    const bool interior = wx0 >= 0 && wx0 + 8*nq <= P.w;
-    WAVE_FOR(l)
+    /* narrow geometry (h264e_dev.h): only 53 columns x 52 rows of the window are ever read */
+    const int rows = narrow ? H264E_NARROW_VH : WIN_W;
+    const bool interior = wx0 >= 0 && wx0 + WIN_W <= P.w;
+    if (interior)
     {
-        if (l < rows)
+        u32x4 v[4];
+        WAVE_FOR(l)
         {
-            const int y = imin(imax(wy0 + l, 0), P.h - 1);
-            if (interior)
-            {
-                const gu8 *src = P.p + (size_t)y*P.stride + wx0;        /* wx0 is a multiple of 8 */
-                uint64_t v[WIN_W/8];
+            const int seg = l & 3;
 #pragma unroll
-                for (int g = 0; g < WIN_W/8; g++) if (g < nq) v[g] = cload64(src + 8*g);
-#pragma unroll
-                for (int g = 0; g < WIN_W/8; g++)
-                    if (g < nq)
-                    {
-                        lds32_store(win + l*WIN_STRIDE + 8*g, (uint32_t)v[g]); lds32_store(win + l*WIN_STRIDE + 8*g + 4, (uint32_t)(v[g] >> 32));
-                    }
-            } else
+            for (int k = 0; k < 4; k++)
             {
+                const int r = (l >> 2) + 16*k;
+                if (r < rows)
+                {
+                    const int y = imin(imax(wy0 + r, 0), P.h - 1);
+                    v[k] = cload128(P.p + (size_t)y*P.stride + wx0 + 16*seg);           /* wx0 is a multiple of 8, rows of 16: dword aligned, the 16 bytes inside one 64-byte segment */
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const int r = (l >> 2) + 16*k;
+                if (r < rows)
+                {
+                    uint8_t *d = win + r*WIN_STRIDE + 16*seg;
+                    lds32_store(d, v[k].x); lds32_store(d + 4, v[k].y); lds32_store(d + 8, v[k].z); lds32_store(d + 12, v[k].w);
+                }
+            }
+        }
+    } else
+    {
+        const int nq = narrow ? (H264E_NARROW_VW + 7)/8 : WIN_W/8;
+        WAVE_FOR(l)
+        {
+            if (l < rows)
+            {
+                const int y = imin(imax(wy0 + l, 0), P.h - 1);
                 for (int g = 0; g < 2*nq; g++) lds32_store(win + l*WIN_STRIDE + 4*g, ref_load4(P, wx0 + 4*g, y));
             }
         }

@@ -320,10 +320,15 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
             const int need = row > row0 ? imin(x + 2, G.nmbx) : 0;
             const int need_dep = RT.dep_progress ? imin(x + DEP_COLS, G.nmbx) : 0;     /* temporal wavefront: h264e_dev.h */
             int st = 0;
-            /* the abort word lives in device memory (raised by a finalizer whose mv_clusters walk failed, or by the host): one L2 read per macroblock */
-            if (abort_word && uni(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == launch_id) st = -2;
+            /* the abort word lives in device memory (raised by a finalizer whose mv_clusters walk failed, or by the host): one L2 read per
+             * macroblock, ISSUED here and looked at behind the window loads -- as is the first look at the row above's counter: three
+             * round trips to L2 / HBM in flight together instead of one after the other (the records above are still loaded BEHIND the
+             * counter that covers them, and behind the acquire) */
+            const int abort_v = abort_word ? __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : launch_id - 1;
+            const GLOBAL_AS int *above = C.progress + (WAVES >= 2 ? G.nmby : 0) + (row - 1);
+            const int early = seen < need ? __hip_atomic_load(above, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seen;
             /* temporal dependency first, then the loads that only need it (input, reference window) ... */
-            if (!st && seen_dep < need_dep)
+            if (seen_dep < need_dep)
             {
                 int lowest = 0x7fffffff;
                 for (int k = 0; k < ndeps && !st; k++)
@@ -341,13 +346,16 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
             STAMP(L, 23);
             if (!st) row_prefetch<GEOM>(L, G, RT, row, x);
             STAMP(L, 0);
+            if (uni(abort_v) == launch_id) st = -2;
             /* ... so that their latency overlaps with the wait for the row above */
             /* two waves: the search needs only the VECTORS of the row above, which that row's reconstruction wave hands over as soon as
              * they are decided (its `decided` counter, behind the progress counters) -- a transform / CAVLC / deblocking earlier than
              * the rest of the record, which this row's reconstruction wave waits for */
             if (!st && seen < need)
             {
-                st = poll_progress(C.progress + (WAVES >= 2 ? G.nmby : 0) + (row - 1), need, seen, G.spin_limit);
+                seen = uni(early);
+                if (seen < 0) st = seen;
+                else if (seen < need) st = poll_progress(above, need, seen, G.spin_limit);
                 if (!st) consumer_acquire();
             }
             STAMP(L, 13);

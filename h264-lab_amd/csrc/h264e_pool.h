@@ -637,11 +637,17 @@ extern "C" int h264e_hip_group_create(h264e_hip_group_t **out, int device)
  * workgroups) ONLY where the whole grid is resident anyway -- its far reads may wait for any workgroup of the grid; 2 in between. */
 #define H264E_RESIDENT_WG_V2 1536
 #define H264E_RESIDENT_WG_V3 512
-static int pick_variant(int forced, int all_intra, int rows, int wgs)
+/* `parallel`: the launch has more independent work than one single-slice stream's temporal wavefront -- several slices per frame,
+ * pictures of 200+ macroblock rows (8K class), several streams merged: only there do the extra resident rows of the 4-per-SIMD kernel
+ * buy more than its 128-register allocation costs (spills in the search; r4 sweep gpurun_out/var_sweep*: 1080p 2 / 4 / 8 slices +5 %,
+ * 8K single slice +34 %, two slices +20 %; a single-slice 1080p / 4K / 720p stream -6 % / -5 % / -3 % -- its passes are bound by the
+ * mis-speculation refills, i.e. by the macroblock latency).  `tree`: the launch carries hedge leaves (rate control): a few frames of
+ * it are ever used, pure latency (1080p 4 Mbit/s: 245 vs 213 fps, 8 slices 413 vs 381). */
+static int pick_variant(int forced, int all_intra, int rows, int wgs, int parallel, int tree)
 {
     if (forced) return forced;
     if (all_intra) return 0;
-    if (rows >= H264E_RESIDENT_WG_V2) return 4;
+    if (rows >= H264E_RESIDENT_WG_V2 && parallel && !tree) return 4;
     if (wgs <= H264E_RESIDENT_WG_V3) return 3;
     return 2;
 }
@@ -691,7 +697,16 @@ static int group_launch_locked(h264e_hip_group_t *g)
         const h264e_geom_t &G = g->member[idx[0]]->G;
         const int rows = G.nmby + 1, lag = narrow ? H264E_NARROW_FRAME_LAG : H264E_FRAME_LAG;
         const size_t total = (size_t)jobs*rows;
-        const int variant = pick_variant(forced, all_intra, jobs*G.nmby, (int)total);
+        /* two or more streams in the grid are parallel work like slices are (a group of one: what h264e_hip_submit would decide) */
+        int parallel = n >= 2 || G.nmby >= 200, tree = 0;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < g->pend_jobs[idx[i]]; j++)
+            {
+                const h264e_frame_task_t &t = g->pend_tasks[idx[i]][j];
+                if (t.active && t.nslices >= 2) parallel = 1;
+                if (t.active && t.walk_quiet) tree = 1;
+            }
+        const int variant = pick_variant(forced, all_intra, jobs*G.nmby, (int)total, parallel, tree);
         if (jobs >= 65536) { GFAIL("group launch: too many jobs"); break; }
         h264e_frame_task_t *th = (h264e_frame_task_t *)malloc(sizeof(h264e_frame_task_t)*(size_t)jobs);
         uint32_t *oh = (uint32_t *)malloc(sizeof(uint32_t)*total);
@@ -850,7 +865,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     if (p->pending >= TASK_RING - 1 && h264e_hip_sync(p)) return -1;
     h264e_frame_task_t *host = (h264e_frame_task_t *)calloc((size_t)p->nchains, sizeof(h264e_frame_task_t));
     if (!host) FAIL("out of host memory");
-    int any = 0, any_narrow = 0, any_wide = 0, njobs = 0, all_intra = 1, max_slices = 1;
+    int any = 0, any_narrow = 0, any_wide = 0, njobs = 0, all_intra = 1, max_slices = 1, any_leaf = 0;
     const int launch_id = ++p->launch_counter;
     for (int c = 0; c < p->nchains; c++)
     {
@@ -867,6 +882,7 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
         any = 1; njobs = c + 1;
         if (t.slice_type != 2) all_intra = 0;
         if (t.nslices > max_slices) max_slices = t.nslices;
+        if (t.stream_mode && t.walk_quiet) any_leaf = 1;
         const uint8_t *f = p->clip + p->frame_bytes*(size_t)t.frame_index;
         d.in[0] = f; d.in[1] = f + (size_t)G.width*G.height; d.in[2] = d.in[1] + (size_t)(G.width/2)*(G.height/2);
         d.in_stride[0] = G.width; d.in_stride[1] = d.in_stride[2] = G.width/2;
@@ -995,13 +1011,10 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
      * search and no events: one wave per row, twice the rows in flight (22.4 vs 18.3 M MB/s at 1080p) */
     /* (waves = 0 selects the intra-only variant of the one-wave kernel: no inter code, half the registers, twice the rows in flight) */
     /* (... and 4 the two-wave kernel allocated for 4 waves per SIMD: launches bound by the rows in flight -- 8K-class pictures, many slices) */
-    /* measured with the final register allocation (gpurun_out/r3_lane4): 4 per SIMD wins wherever a launch offers enough rows to fill the
-     * chip (8 slices 20.6 -> 23.3 M MB/s, 8K 6.6 -> 9.1 M, 4K 14.8 -> 15.3 M, 1080p single slice 9.56 -> 9.61 M); launches of a few frames
-     * (rate control, the frame-at-a-time API) are pure latency and keep the 3-per-SIMD kernel with its fewer spills (10.5 vs 10.9 ms) */
+    /* which launches that is: pick_variant above (re-measured in round 4 with the slimmer macroblock step) */
     /* (... and 3 the latency variant -- four waves per row: the 8x8 partition search and the deblocking + stores on waves of their own:
      * launches of one or a few frames, where the chip is empty and only the macroblock latency counts: the frame-at-a-time API) */
-    const int waves = pick_variant(p->waves, all_intra, njobs*G.nmby, njobs*(G.nmby + 1));
-    (void)max_slices;
+    const int waves = pick_variant(p->waves, all_intra, njobs*G.nmby, njobs*(G.nmby + 1), max_slices >= 2 || G.nmby >= 200, any_leaf);
     if (p->group)
     {
         /* member of a launch group: the launch is merged with the other members' and the variant is chosen from the MERGED grid

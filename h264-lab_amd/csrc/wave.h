@@ -570,6 +570,7 @@ DEV void gstore32(gu8 *p, uint32_t v) { EMU_GLOBAL(p, 4); *(gu32u *)p = v; }
 #define H264E_PLAIN_UNALIGNED_LOADS 0
 DEV uint32_t cload32(const gu8 *p) { uint32_t v; EMU_GLOBAL(p, 4); memcpy(&v, p, 4); return v; }
 DEV uint64_t cload64(const gu8 *p) { uint64_t v; EMU_GLOBAL(p, 8); memcpy(&v, p, 8); return v; }
+DEV u32x4 cload128(const gu8 *p) { u32x4 v; EMU_GLOBAL(p, 16); memcpy(&v, p, 16); return v; }
 DEV void cstore32(gu8 *p, uint32_t v) { EMU_GLOBAL(p, 4); memcpy(p, &v, 4); }
 DEV void cstore64(gu8 *p, uint64_t v) { EMU_GLOBAL(p, 8); memcpy(p, &v, 8); }
 #else
@@ -587,6 +588,7 @@ DEV void consumer_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefron
 #else
 DEV uint32_t cload32(const gu8 *p) { return *(const GLOBAL_AS uint32_t *)p; }
 DEV uint64_t cload64(const gu8 *p) { return *(const GLOBAL_AS uint64_t *)p; }
+DEV u32x4 cload128(const gu8 *p) { return *(const GLOBAL_AS u32x4 *)p; }           /* 16 bytes, dword aligned (plain, behind the hand-off's acquire) */
 DEV void consumer_acquire()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

@@ -1,11 +1,12 @@
 #!/bin/bash
-# one-off GPU visit: issue priorities (s_setprio by position in the launch) on / off
-cd ${GRAFT_REPO_ROOT:-.}
+# scratch experiment visit: slice counts and concurrent streams under forced kernel variants
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/${1:-exp}; mkdir -p $OUT; cd $R
 export H264E_QUIET=1
-for p in 0 1; do
-  echo "--- H264E_PRIO=$p"
-  for cfg in "600 1920 1080 30 26 0 0" "600 1920 1080 30 26 8 0" "60 1920 1080 30 26 0 4000" "60 1920 1080 30 26 8 4000" "240 3840 2160 30 26 0 0" "3000 352 288 30 26 0 0"; do H264E_PRIO=$p timeout -k 10 200 python tools/clip_debug.py $cfg 2>/dev/null | tail -1; done
-  H264E_PRIO=$p timeout -k 10 120 python tools/single_frame_latency.py
+for w in 2 4; do
+  for cfg in "600 1920 1080 30 26 2 0" "600 1920 1080 30 26 4 0" "240 3840 2160 30 26 2 0" "240 3840 2160 30 26 4 0" "60 7680 4320 30 26 2 0" "600 1280 720 30 26 8 0"; do
+    echo "H264E_WAVES=$w $cfg" >> $OUT/var.txt
+    H264E_WAVES=$w timeout -k 10 200 python tools/clip_debug.py $cfg 2>/dev/null | tail -1 >> $OUT/var.txt || exit 1
+  done
+  for b in 2 4; do echo "H264E_WAVES=$w streams $b" >> $OUT/var.txt; H264E_WAVES=$w timeout -k 10 300 python tools/multi_clip_probe.py $b 600 2>&1 | tail -1 >> $OUT/var.txt || exit 1; done
 done
-unset H264E_QUIET
-H264E_PRIO=1 timeout -k 10 200 python tools/clip_debug.py 600 1920 1080 30 26 0 0 2>&1 | tail -26 | cut -c1-200
+cat $OUT/var.txt
