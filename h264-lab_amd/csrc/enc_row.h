@@ -1,9 +1,9 @@
 /*
- * enc_row.h -- row driver (row_begin / row_step / row_end) and the slice splice (finalize_frame), wave64 model.
+ * enc_row.h -- row driver (row_begin / row_step / row_end) and the slice splice (splice_frame / finalize_commit), wave64 model.
  *
  * row_step = the reference's mb_encode (h264-lab.h:5724-5812) for macroblock (x, row): neighbour records of
  * the row above come from HBM (written by that row's wavefront), the left neighbour is in LDS.
- * finalize_frame = the tail of encode_slice (h264-lab.h:6451-6456): concatenates the row bit buffers behind
+ * splice_frame = the tail of encode_slice (h264-lab.h:6451-6456): concatenates the row bit buffers behind
  * the slice header, resolves mb_skip_run across rows, adds the RBSP trailing bits, and evaluates the
  * mv_clusters speculation.
  */
@@ -597,72 +597,116 @@ DEV void clusters_step(mv32 c[2], mv32 mv)                                  /* h
  * finds the next one that moves it or mismatches, everything in front of it is settled at once.  traj (optional) receives the
  * state in front of every macroblock.  Returns the first mismatching macroblock or -1; s = state behind the frame.
  */
+/* macroblocks [k0, k1) of one slice, continuing from state s / verdict first_bad (the finalizer walks a frame row by row as its rows
+ * complete; batches of 64 inside the range) */
+DEV void clusters_walk_range(const h264e_frame_task_t &T, const GLOBAL_AS h264e_mbrec_t *rec, mv32 s[2], int &first_bad, GLOBAL_AS mv32 *traj, int k0, int k1)
+{
+    const GLOBAL_AS mv32 *per_mb = (const GLOBAL_AS mv32 *)T.clusters_per_mb;
+    const mv32 u_frame0 = T.clusters[0], u_frame1 = T.clusters[1];
+    for (int base = k0; base < k1; base += 64)
+    {
+        int start = 0;
+        /* the state in front of every macroblock of the batch, one per lane (wave.h V64) */
+        V64 mine0 = v64_make([&](int) -> int { return s[0]; }), mine1 = v64_make([&](int) -> int { return s[1]; });
+        for (;;)
+        {
+            const mv32 c0 = s[0], c1 = s[1];
+            const int fb = first_bad;
+            const uint64_t ev = wave_ballot([&](int l) -> int {
+                const int k = base + l;
+                if (l < start || k >= k1) return 0;
+                const mv32 mv0 = rec[k].mv0;
+                const int type = rec[k].type;
+                int hit = 0;
+                if (fb < 0 && rec[k].used_cand)
+                {
+                    const mv32 u0 = per_mb ? per_mb[2*k] : u_frame0, u1 = per_mb ? per_mb[2*k + 1] : u_frame1;
+                    if (mvround(u0) != mvround(c0) || mvround(u1) != mvround(c1)) hit = 1;
+                }
+                if (type < 5)
+                {
+                    mv32 c[2] = { c0, c1 };
+                    clusters_step(c, mv0);
+                    if (c[0] != c0 || c[1] != c1) hit = 1;
+                }
+                return hit;
+            });
+            if (!ev) break;
+            const int e = __builtin_ctzll(ev), ke = base + e;
+            /* macroblock ke: mismatch check first (against the state in front of it), then its update */
+            if (first_bad < 0 && rec[ke].used_cand)
+            {
+                const mv32 u0 = per_mb ? per_mb[2*ke] : u_frame0, u1 = per_mb ? per_mb[2*ke + 1] : u_frame1;
+                if (mvround(u0) != mvround(s[0]) || mvround(u1) != mvround(s[1])) first_bad = ke;
+            }
+            if (rec[ke].type < 5) clusters_step(s, rec[ke].mv0);
+            s[0] = (mv32)uni(s[0]); s[1] = (mv32)uni(s[1]); first_bad = uni(first_bad);
+            start = e + 1;
+            mine0 = v64_map(mine0, [&](int l, int v) -> int { return l >= start ? s[0] : v; });
+            mine1 = v64_map(mine1, [&](int l, int v) -> int { return l >= start ? s[1] : v; });
+            if (start >= 64) break;
+        }
+        if (traj)
+        {
+            v64_each(mine0, [&](int l, int v) { const int k = base + l; if (k < k1) traj[2*k] = v; });
+            v64_each(mine1, [&](int l, int v) { const int k = base + l; if (k < k1) traj[2*k + 1] = v; });
+        }
+    }
+}
+
+/* the whole frame at once (the walk of a complete frame: tests, tools) */
 DEV int device_clusters_walk(const h264e_geom_t &G, const h264e_frame_task_t &T, const GLOBAL_AS h264e_mbrec_t *rec, mv32 s[2], GLOBAL_AS mv32 *traj)
 {
     const mv32 s0[2] = { s[0], s[1] };
-    const GLOBAL_AS mv32 *per_mb = (const GLOBAL_AS mv32 *)T.clusters_per_mb;
-    const mv32 u_frame0 = T.clusters[0], u_frame1 = T.clusters[1];
     int first_bad = -1;
     for (int band = 0; band < T.nslices; band++)
     {
-        const int k0 = T.slice_row[band]*G.nmbx, k1 = T.slice_row[band + 1]*G.nmbx;
         s[0] = s0[0]; s[1] = s0[1];
-        for (int base = k0; base < k1; base += 64)
-        {
-            int start = 0;
-            /* the state in front of every macroblock of the batch, one per lane (wave.h V64) */
-            V64 mine0 = v64_make([&](int) -> int { return s[0]; }), mine1 = v64_make([&](int) -> int { return s[1]; });
-            for (;;)
-            {
-                const mv32 c0 = s[0], c1 = s[1];
-                const int fb = first_bad;
-                const uint64_t ev = wave_ballot([&](int l) -> int {
-                    const int k = base + l;
-                    if (l < start || k >= k1) return 0;
-                    const mv32 mv0 = rec[k].mv0;
-                    const int type = rec[k].type;
-                    int hit = 0;
-                    if (fb < 0 && rec[k].used_cand)
-                    {
-                        const mv32 u0 = per_mb ? per_mb[2*k] : u_frame0, u1 = per_mb ? per_mb[2*k + 1] : u_frame1;
-                        if (mvround(u0) != mvround(c0) || mvround(u1) != mvround(c1)) hit = 1;
-                    }
-                    if (type < 5)
-                    {
-                        mv32 c[2] = { c0, c1 };
-                        clusters_step(c, mv0);
-                        if (c[0] != c0 || c[1] != c1) hit = 1;
-                    }
-                    return hit;
-                });
-                if (!ev) break;
-                const int e = __builtin_ctzll(ev), ke = base + e;
-                /* macroblock ke: mismatch check first (against the state in front of it), then its update */
-                if (first_bad < 0 && rec[ke].used_cand)
-                {
-                    const mv32 u0 = per_mb ? per_mb[2*ke] : u_frame0, u1 = per_mb ? per_mb[2*ke + 1] : u_frame1;
-                    if (mvround(u0) != mvround(s[0]) || mvround(u1) != mvround(s[1])) first_bad = ke;
-                }
-                if (rec[ke].type < 5) clusters_step(s, rec[ke].mv0);
-                s[0] = (mv32)uni(s[0]); s[1] = (mv32)uni(s[1]); first_bad = uni(first_bad);
-                start = e + 1;
-                mine0 = v64_map(mine0, [&](int l, int v) -> int { return l >= start ? s[0] : v; });
-                mine1 = v64_map(mine1, [&](int l, int v) -> int { return l >= start ? s[1] : v; });
-                if (start >= 64) break;
-            }
-            if (traj)
-            {
-                v64_each(mine0, [&](int l, int v) { const int k = base + l; if (k < k1) traj[2*k] = v; });
-                v64_each(mine1, [&](int l, int v) { const int k = base + l; if (k < k1) traj[2*k + 1] = v; });
-            }
-        }
+        clusters_walk_range(T, rec, s, first_bad, traj, T.slice_row[band]*G.nmbx, T.slice_row[band + 1]*G.nmbx);
     }
     if (T.nslices > 1) { s[0] = s0[0]; s[1] = s0[1]; }      /* the parent's state never moves in the row-band build (h264-lab.h:6526) */
     wave_sync();
     return first_bad;
 }
 
-DEV void finalize_frame(const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, GLOBAL_AS int *stepflags)
+/*
+ * The finalizer's walk, ROW BY ROW as the rows complete (JobWalk::rows is called from the splice below, for the rows whose counters say
+ * complete, once the state in front of the frame is known): the verdict of a frame is known a walk of ONE row after its last row ended.
+ * The walk goes on behind a mismatch, over every row, as the whole-frame walk does: the trajectory behind the mismatch is the speculation
+ * for the next encode of those rows, and it is a good one (the vectors of macroblocks that consumed slightly wrong candidates are mostly
+ * the right ones).  Stopping the launch as soon as the row with the first mismatch has ended, with the state at the stop as the
+ * trajectory of everything behind it, was built and measured in round 4: it wins a little where a frame fails once (1080p 4 Mbit/s:
+ * +2.5 %) and loses badly where the state keeps moving through a frame (8K 60 Mbit/s, two slices: 50 launches instead of 22, the
+ * re-encodes advance two or three rows at a time) -- not kept.
+ */
+struct JobWalk
+{
+    mv32 s0[2], s[2];
+    int first_bad, next_row;
+    DEVM void begin(const mv32 st[2]) { s0[0] = s[0] = st[0]; s0[1] = s[1] = st[1]; first_bad = -1; next_row = 0; }
+    /* walks the rows up to and including `upto` that have not been walked yet (all of them complete) */
+    DEVM void rows(const h264e_geom_t &G, const h264e_frame_task_t &T, const GLOBAL_AS h264e_mbrec_t *rec, GLOBAL_AS mv32 *traj, int upto)
+    {
+        for (; next_row <= upto; next_row++)
+        {
+            const int r = next_row;
+            for (int k = 0; k < T.nslices; k++) if (r == T.slice_row[k]) { s[0] = s0[0]; s[1] = s0[1]; }      /* every slice starts from the state in front of the frame */
+            clusters_walk_range(T, rec, s, first_bad, traj, r*G.nmbx, (r + 1)*G.nmbx);
+        }
+    }
+    /* behind the last row: the state to hand on */
+    DEVM void end(const h264e_frame_task_t &T)
+    {
+        if (T.nslices > 1) { s[0] = s0[0]; s[1] = s0[1]; }      /* the parent's state never moves in the row-band build (h264-lab.h:6526) */
+        wave_sync();
+    }
+};
+
+struct SpliceOut { uint32_t start, nbytes; int overflow, all_skipped; };
+
+/* The slices' RBSPs from the row bit buffers.  on_row(first row of the slice, row) is called before a row is touched: the caller waits
+ * for the row there (and walks it); a non-zero return ends the splice with that code (nothing is committed). */
+template <class ROW> DEV int splice_frame(const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, SpliceOut &o, ROW on_row)
 {
     SpliceState s;
     const uint32_t start = T.arena_reset ? 0u : ((*C.cursor + 15u) & ~15u);
@@ -683,6 +727,8 @@ DEV void finalize_frame(const h264e_geom_t &G, const ChainG &C, const h264e_fram
         int run = 0;
         for (int row = r0; row < r1; row++)
         {
+            const int stop = on_row(r0, row);
+            if (stop) return stop;
             const GLOBAL_AS h264e_rowmeta_t &M = C.rowmeta[row];
             overflow |= M.overflow;
             run += M.lead_skips;
@@ -706,13 +752,19 @@ DEV void finalize_frame(const h264e_geom_t &G, const ChainG &C, const h264e_fram
         if (k + 1 < T.nslices) off += (nbytes + 15u) & ~15u; else off += nbytes;
         wave_sync();
     }
-    const uint32_t nbytes = off;
-    s.overflow = spl_overflow;
+    o.start = start; o.nbytes = off; o.overflow = overflow | spl_overflow; o.all_skipped = all_skipped;
+    return 0;
+}
 
-    /* mv_clusters speculation check: is the speculated state a fixed point of every update of this frame? */
+/* ... and the frame's result record, once the frame stands */
+DEV void finalize_commit(const h264e_geom_t &G, const ChainG &C, const h264e_frame_task_t &T, const SpliceOut &o, GLOBAL_AS int *stepflags)
+{
+    GLOBAL_AS h264e_frameout_t &F = C.fout[T.frame_slot];
+    /* mv_clusters speculation check of the frame-at-a-time path (its host walks exactly when this says "moved"): is the speculated state
+     * a fixed point of every update of this frame?  Frames validated by the device walk do not need it. */
     const GLOBAL_AS h264e_mbrec_t *rec = C.mbrec + (size_t)T.frame_slot*G.nmb;
     int moved = 0;
-    if (!T.clusters_per_mb)
+    if (!T.clusters_per_mb && !T.walk_on_device)
     {
         for (int base = 0; base < G.nmb; base += 64)
         {
@@ -726,17 +778,17 @@ DEV void finalize_frame(const h264e_geom_t &G, const ChainG &C, const h264e_fram
             if (bad) moved = 1;
         }
     }
-    F.offset = start;
-    F.nbytes = nbytes;
+    F.offset = o.start;
+    F.nbytes = o.nbytes;
     F.nslices = T.nslices;
-    F.all_skipped = all_skipped;
+    F.all_skipped = o.all_skipped;
     F.clusters_moved = moved;
-    F.overflow = overflow | s.overflow;
+    F.overflow = o.overflow;
     F.far_reads = g_atomic_load(C.far_reads);
     if (wave_lane() == 0) g_atomic_store(C.far_reads, 0);
-    *C.cursor = start + ((nbytes + 15u) & ~15u);
+    *C.cursor = o.start + ((o.nbytes + 15u) & ~15u);
     stepflags[0] = moved;
-    stepflags[1] = overflow | s.overflow;
+    stepflags[1] = o.overflow;
     wave_sync();
 }
 

@@ -51,6 +51,7 @@ typedef struct
     int row_words;                      /* 32-bit words per row bit buffer */
     unsigned spin_limit;                /* bound of every in-kernel wait (polls with s_sleep between them); expiry = reported failure */
     int test_stall_row;                 /* fault injection (tests): this macroblock row of job 0 exits without ever publishing; -1 = off */
+    int fz_wait_all;                    /* A/B measurements (H264E_FZ_WAIT_ALL=1): the finalizer waits for ALL rows of its frame before it walks / splices any */
 } h264e_geom_t;
 
 typedef struct

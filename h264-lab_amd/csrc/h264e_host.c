@@ -1426,9 +1426,13 @@ int H264E_clip_encode(H264E_clip_t *c, uint8_t *out, size_t cap, size_t *out_byt
             }
         } else if (c->narrow_ok && c->next >= c->wide_until) { c->narrow = 1; c->far_acc = 0; c->far_frames = 0; }
         if (getenv("H264E_DEBUG"))
+        {
+            const double t_end = now_ms();
+            if (!nvalid) t_first = t_last = t_end;              /* no frame of it was delivered: "first frame after" = when its verdict was in */
             fprintf(stderr, "clip launch %d (first row %d, %s window, %lld far reads): %d frames in flight, %d valid, next %d; first frame after %.2f ms, then %.3f ms/frame, drained %.2f ms after the last; ended by: %s%s\n",
-                    stats.rounds, tasks[0].first_row, tasks[0].narrow_window ? "narrow" : "wide", far_reads, F, nvalid, c->next, t_first - t_submit, nvalid > 1 ? (t_last - t_first)/(nvalid - 1 + (nvalid < F)) : 0.0, now_ms() - t_last,
+                    stats.rounds, tasks[0].first_row, tasks[0].narrow_window ? "narrow" : "wide", far_reads, F, nvalid, c->next, t_first - t_submit, nvalid > 1 ? (t_last - t_first)/(nvalid - 1 + (nvalid < F)) : 0.0, t_end - t_last,
                     full ? "output buffer full" : why, nh ? " (+ hedge leaves)" : "");
+        }
         if (full && c->next == first)
         {
             snprintf(g_host_err, sizeof(g_host_err), "output buffer too small for one frame");

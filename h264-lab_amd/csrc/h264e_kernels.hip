@@ -167,13 +167,97 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
         int st = 0, seen = 0;
         GLOBAL_AS h264e_hostdone_t *hd = (GLOBAL_AS h264e_hostdone_t *)T.host_done;
         GLOBAL_AS h264e_walkrec_t *wout = (GLOBAL_AS h264e_walkrec_t *)T.walk_out;
-        for (int r = G.nmby - 1; r >= 0 && !st; r--) st = poll_progress(C.progress + r, G.nmbx + 1, seen, G.spin_limit);
-        if (st)
+        /* The finalizer follows its frame ROW BY ROW (enc_row.h JobWalk / splice_frame): a row whose counter says complete is spliced
+         * while the rows below it are still being encoded, and walked (exact mv_clusters validation) as soon as the state in front of
+         * the frame is known -- the verdict of the frame in front, which usually arrives when this frame is nearly done: the rows
+         * completed by then are walked in one go (also while this wave waits for its next row: the frame-to-frame chain of verdicts
+         * must carry the walk alone, never a wait or the splice), and the verdict goes out right behind the walk of the last row. */
+        int wstatus = 0, first_bad = -1, have_prev = !(T.walk_on_device && T.walk_prev), published = 0;
+        mv32 ws[2] = { T.exact_state[0], T.exact_state[1] };
+        const GLOBAL_AS h264e_walkrec_t *wp = (const GLOBAL_AS h264e_walkrec_t *)T.walk_prev;
+        const GLOBAL_AS h264e_mbrec_t *rec = C.mbrec + (size_t)T.frame_slot*G.nmb;
+        JobWalk W;
+        W.begin(ws);
+        /* Row-band slices: every slice of every frame starts from the state in front of the STREAM (the parent's state never moves,
+         * h264-lab.h:6526), so the walk needs nothing of the frame in front but its status, and only to publish: the chain of verdicts
+         * carries no walk at all (it was what bounded an 8-slice stream: one walk of ~0.26 ms per frame, 3830 frames/s) */
+        const bool state_fixed = T.nslices > 1;
+        /* the verdict of the frame in front has arrived: take its state (or its failure) */
+        const auto take_prev = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (uni(wp->status) != H264E_WALK_OK) wstatus = H264E_WALK_VOID;
+            else if (!state_fixed) { ws[0] = (mv32)uni(wp->state_out[0]); ws[1] = (mv32)uni(wp->state_out[1]); W.begin(ws); }
+            have_prev = 1;
+        };
+        /* this frame's verdict, for the frame behind */
+        const auto publish_verdict = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (LANE == 0 && wout)
+            {
+                wout->state_out[0] = ws[0]; wout->state_out[1] = ws[1]; wout->status = wstatus; wout->first_bad = first_bad;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&wout->flag, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            published = 1;
+        };
+        /* rows up to `upto` are complete: walk what the walk may have; behind the last row the verdict goes out.  Returns non-zero
+         * when the frame does not stand (mismatch, or void because the frame in front does not) */
+        const auto walk_upto = [&](int upto) -> int {
+            if (!T.walk_on_device || published) return 0;
+            if (!have_prev && uni(__hip_atomic_load(&wp->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= T.launch_id) take_prev();
+            if (!have_prev && !state_fixed) return 0;
+            if (!wstatus)
+            {
+                W.rows(G, T, rec, (GLOBAL_AS mv32 *)T.traj_out, upto);
+                if (W.next_row < G.nmby) return 0;
+                if (!have_prev)
+                {
+                    /* walked to the end on the fixed state: the verdict still has to wait for the status of the frame in front */
+                    int sf = 0;
+                    if (poll_progress(&wp->flag, T.launch_id, sf, G.spin_limit)) { wstatus = H264E_WALK_VOID; have_prev = 1; }
+                    else take_prev();
+                }
+            }
+            if (!wstatus)
+            {
+                W.end(T);
+                first_bad = W.first_bad;
+                ws[0] = W.s[0]; ws[1] = W.s[1];
+                wstatus = first_bad >= 0 ? H264E_WALK_BAD : H264E_WALK_OK;
+            }
+            publish_verdict();
+            return wstatus != H264E_WALK_OK;
+        };
+        SpliceOut so;
+        if (G.fz_wait_all) for (int r = G.nmby - 1; r >= 0 && !st; r--) st = poll_progress(C.progress + r, G.nmbx + 1, seen, G.spin_limit);
+        if (!st) st = splice_frame(G, C, T, so, [&](int, int r) -> int {
+            for (unsigned spins = 0;; spins++)
+            {
+                seen = uni(__hip_atomic_load(C.progress + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (seen >= G.nmbx + 1) break;
+                if (seen < 0) return seen;
+                if (spins > G.spin_limit) return -1;
+                /* waiting for row r: the rows above it are complete (and acquired) -- is their walk due? */
+                if (r > 0 && walk_upto(r - 1)) return 1;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            return walk_upto(r);
+        });
+        FZ_STAMP(32);               /* followed the frame's rows: waits, the splice of every completed row, the walk once its start state was in */
+        if (st < 0)
         {
+            /* a row of the frame was stopped or failed */
             if (LANE == 0)
             {
                 if (st == -1) *errflag = 1;
-                if (T.walk_on_device && wout)
+                if (T.walk_on_device && wout && !published)
                 {
                     /* the frames behind wait for this verdict: never leave them spinning */
                     wout->status = H264E_WALK_VOID; wout->first_bad = -1;
@@ -185,50 +269,26 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
             }
             return;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        FZ_STAMP(32);               /* waited for the frame's rows */
-        int wstatus = 0, first_bad = -1;
-        mv32 ws[2] = { T.exact_state[0], T.exact_state[1] };
         if (T.walk_on_device)
         {
-            /* exact mv_clusters validation on the device: start from the verdict of the frame in front (same launch), walk this
-             * frame's records, publish the verdict for the frame behind; a mismatch stops the whole launch through the abort word */
-            if (T.walk_prev)
+            if (!published)
             {
-                const GLOBAL_AS h264e_walkrec_t *wp = (const GLOBAL_AS h264e_walkrec_t *)T.walk_prev;
-                int sf = 0;
-                if (poll_progress(&wp->flag, T.launch_id, sf, G.spin_limit)) wstatus = H264E_WALK_VOID;
-                else
+                /* every row is spliced and the state in front of the frame is still out: wait for it, walk the frame in one go */
+                if (!have_prev)
                 {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();
-                    if (uni(wp->status) != H264E_WALK_OK) wstatus = H264E_WALK_VOID;
-                    else { ws[0] = (mv32)uni(wp->state_out[0]); ws[1] = (mv32)uni(wp->state_out[1]); }
+                    int sf = 0;
+                    if (poll_progress(&wp->flag, T.launch_id, sf, G.spin_limit)) { wstatus = H264E_WALK_VOID; have_prev = 1; }
+                    else take_prev();
                 }
-            }
-            FZ_STAMP(33);           /* waited for the verdict of the frame in front */
-            if (!wstatus)
-            {
-                first_bad = device_clusters_walk(G, T, C.mbrec + (size_t)T.frame_slot*G.nmb, ws, (GLOBAL_AS mv32 *)T.traj_out);
-                wstatus = first_bad >= 0 ? H264E_WALK_BAD : H264E_WALK_OK;
-            }
-            FZ_STAMP(34);           /* the exact walk of the frame's records: the serial chain from frame to frame */
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            if (LANE == 0 && wout)
-            {
-                wout->state_out[0] = ws[0]; wout->state_out[1] = ws[1]; wout->status = wstatus; wout->first_bad = first_bad;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&wout->flag, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                FZ_STAMP(33);       /* waited for the verdict of the frame in front */
+                (void)walk_upto(G.nmby - 1);
+                FZ_STAMP(34);       /* the exact walk behind the splice (the frame in front was late) */
             }
             if (wstatus != H264E_WALK_OK)
             {
                 if (LANE == 0)
                 {
+                    /* a mismatch stops the whole launch through the abort word (a leaf's concerns nobody but itself) */
                     if (wstatus == H264E_WALK_BAD && T.abort_word && !T.walk_quiet)
                         __hip_atomic_store((GLOBAL_AS int *)T.abort_word, T.launch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (hd)
@@ -242,8 +302,8 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
                 return;
             }
         }
-        finalize_frame(G, C, T, (GLOBAL_AS int *)T.stepflags);
-        FZ_STAMP(35);               /* slice splice */
+        finalize_commit(G, C, T, so, (GLOBAL_AS int *)T.stepflags);
+        FZ_STAMP(35);               /* the last row's splice + the result record */
         if (hd)
         {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");

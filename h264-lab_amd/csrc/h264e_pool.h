@@ -334,6 +334,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
     const int knobs = getenv("H264E_TEST_KNOBS") && atoi(getenv("H264E_TEST_KNOBS")) == 1;
     G.spin_limit = 1u << 24;
     G.test_stall_row = -1;
+    G.fz_wait_all = getenv("H264E_FZ_WAIT_ALL") ? atoi(getenv("H264E_FZ_WAIT_ALL")) : 0;
     p->test_upload_fail_at = -1;
     if (knobs)
     {

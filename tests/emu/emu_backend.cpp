@@ -74,19 +74,28 @@ static void bk_launch_mb(const h264e_geom_t &G, int narrow, int variant, unsigne
             row_end(*L, G, C, row);
             free(L);
         }
-        /* the job's finalizer (h264e_kernels.hip, workgroup `nmby`) */
+        /* the job's finalizer (h264e_kernels.hip, workgroup `nmby`): the same row-by-row walk + splice; every row is complete here */
         int wstatus = 0, first_bad = -1;
         mv32 ws[2] = { T.exact_state[0], T.exact_state[1] };
+        if (T.walk_on_device && T.walk_prev)
+        {
+            if (T.walk_prev->flag != T.launch_id || T.walk_prev->status != H264E_WALK_OK) wstatus = H264E_WALK_VOID;
+            else { ws[0] = T.walk_prev->state_out[0]; ws[1] = T.walk_prev->state_out[1]; }
+        }
+        JobWalk W;
+        W.begin(ws);
+        SpliceOut so;
+        const bool walking = T.walk_on_device && !wstatus;
+        const h264e_mbrec_t *rec = C.mbrec + (size_t)T.frame_slot*G.nmb;
+        if (!wstatus)
+            (void)splice_frame(G, C, T, so, [&](int, int r) -> int { if (walking) W.rows(G, T, rec, T.traj_out, r); return 0; });
         if (T.walk_on_device)
         {
-            if (T.walk_prev)
-            {
-                if (T.walk_prev->flag != T.launch_id || T.walk_prev->status != H264E_WALK_OK) wstatus = H264E_WALK_VOID;
-                else { ws[0] = T.walk_prev->state_out[0]; ws[1] = T.walk_prev->state_out[1]; }
-            }
             if (!wstatus)
             {
-                first_bad = device_clusters_walk(G, T, C.mbrec + (size_t)T.frame_slot*G.nmb, ws, T.traj_out);
+                W.end(T);
+                first_bad = W.first_bad;
+                ws[0] = W.s[0]; ws[1] = W.s[1];
                 wstatus = first_bad >= 0 ? H264E_WALK_BAD : H264E_WALK_OK;
             }
             if (T.walk_out) { T.walk_out->state_out[0] = ws[0]; T.walk_out->state_out[1] = ws[1]; T.walk_out->status = wstatus; T.walk_out->first_bad = first_bad; T.walk_out->flag = T.launch_id; }
@@ -100,7 +109,7 @@ static void bk_launch_mb(const h264e_geom_t &G, int narrow, int variant, unsigne
                 continue;
             }
         }
-        finalize_frame(G, C, T, T.stepflags);
+        finalize_commit(G, C, T, so, T.stepflags);
         if (T.host_done)
         {
             uint32_t nal_bytes[H264E_MAX_SLICES], nal_total = 0;

@@ -49,8 +49,8 @@ def main():
         print("mb_write: luma transform + quantiser + reconstruction %.0f cycles/MB (of the mb_write line above; the CAVLC of the residual blocks measured 2.3 k)" % (t[30] / nmb))
     if t[37]:
         nf = t[37]
-        print("finalizer workgroups (%d frames), microseconds per frame: wait for the frame's rows %.1f | wait for the verdict of the frame in front %.1f | exact walk of the records %.1f | slice splice %.1f | NAL escaping + export %.1f" %
-              (nf, t[32] / nf / 100.0, t[33] / nf / 100.0, t[34] / nf / 100.0, t[35] / nf / 100.0, t[36] / nf / 100.0))
+        print("finalizer workgroups (%d frames), microseconds per frame: wait for the verdict of the frame in front %.1f | follow the frame's rows (wait; walk + splice of each completed row) %.1f | end of the walk %.1f | last row's splice + result record %.1f | NAL escaping + export %.1f" %
+              (nf, t[33] / nf / 100.0, t[32] / nf / 100.0, t[34] / nf / 100.0, t[35] / nf / 100.0, t[36] / nf / 100.0))
     if t[29]:
         print("effective shader clock over the rows' lifetimes: %.0f MHz (cycle counter / 100 MHz wall clock)" % (100.0 * t[28] / t[29]))
 
