@@ -23,6 +23,18 @@ def main():
             line = [l for l in open(p).read().splitlines() if l.startswith("{")]
             if line:
                 open(os.path.join(dst, out % tag), "w").write(line[-1] + "\n")
+    # the variant the launches ran (kernel trace), and what the stream counted itself (bench line taken under the trace)
+    kname = "h264e_mb_kernel"
+    for l in open(os.path.join(src, "kernel_stats.csv")):
+        if "h264e_mb_kernel" in l:
+            kname = l.split('"')[1].replace("void ", "").split("(")[0] + "  (GEOM 1 = narrow window, WAVES per macroblock row, waves per SIMD aimed at)"
+            break
+    processed = None
+    p = os.path.join(src, "bench_line_under_trace.json")
+    if os.path.exists(p):
+        line = [l for l in open(p).read().splitlines() if l.startswith("{")]
+        if line:
+            processed = json.loads(line[-1]).get("config", {}).get("processed_mb_per_step")
     c = json.load(open(os.path.join(src, "counters.json")))
     cn, ln = c["counters"], c["launches"]
     passes = 3                                   # warmup 1 + steps 2
@@ -33,11 +45,13 @@ def main():
     total = (fetch_kb + write_kb)*1024.0
     json.dump({
         "command": "rocprofv3 --pmc FETCH_SIZE (and, in a separate run, --pmc WRITE_SIZE) -- " + cmd,
-        "kernel": "h264e_mb_kernel<true, 2> (narrow window geometry, two wavefronts per macroblock row)",
+        "kernel": kname,
         "counters": {"FETCH_SIZE": {"launches": ln["FETCH_SIZE"], "sum_kb": cn["FETCH_SIZE"], "kb_per_launch": fetch_kb},
                      "WRITE_SIZE": {"launches": ln["WRITE_SIZE"], "sum_kb": cn["WRITE_SIZE"], "kb_per_launch": write_kb}},
         "bytes_per_launch": total, "algorithmic_read_bytes_per_launch": rd, "algorithmic_read_write_bytes_per_launch": rw,
         "ratio_vs_algorithmic_read_write": total/rw,
+        "processed_macroblocks_per_pass": processed,
+        "ratio_per_processed_macroblock": (total/rw)*(FRAMES*NMB)/processed if processed else None,
         "note": "raw counter values (KB) per launch, FETCH + WRITE; on gfx950 FETCH_SIZE under-reports wide streaming reads by up to 2x (MI355X_MICROARCH.md) "
                 "and is uncalibrated for the 4..8-byte accesses of this kernel, so the fetch part lies between the raw value and twice it. About half of the "
                 "macroblocks processed in a pass belong to frames thrown away at a mis-speculation abort."}, open(os.path.join(dst, "%s_pmc_traffic.json" % tag), "w"), indent=1)
@@ -56,6 +70,9 @@ def main():
         "insts_per_useful_macroblock": {"note": "%d passes x %d macroblocks of the stream (work thrown away at aborts is in the numerator only)" % (passes, FRAMES*NMB),
                                         "salu": cn["SQ_INSTS_SALU"]/useful, "valu": cn["SQ_INSTS_VALU"]/useful, "lds": cn["SQ_INSTS_LDS"]/useful,
                                         "vmem": (cn["SQ_INSTS_VMEM_RD"] + cn["SQ_INSTS_VMEM_WR"])/useful},
+        "insts_per_processed_macroblock": ({"note": "per macroblock the rows actually got through (the kernel's own counter, bench line: %d per pass)" % processed,
+                                            "salu": cn["SQ_INSTS_SALU"]/(processed*passes), "valu": cn["SQ_INSTS_VALU"]/(processed*passes),
+                                            "lds": cn["SQ_INSTS_LDS"]/(processed*passes)} if processed else None),
         "wave_cycle_shares": {"parked (SQ_WAIT_ANY)": cn["SQ_WAIT_ANY"]/cn["SQ_WAVE_CYCLES"], "issue stalls (SQ_WAIT_INST_ANY)": cn["SQ_WAIT_INST_ANY"]/cn["SQ_WAVE_CYCLES"],
                               "issuing (SQ_ACTIVE_INST_ANY)": cn["SQ_ACTIVE_INST_ANY"]/cn["SQ_WAVE_CYCLES"]},
         "definition": "x_issue_frac = instructions x 4 cycles / (1024 SIMDs x kernel cycles): a wave64 VALU instruction holds its SIMD for 4 cycles, the scalar unit serves "
