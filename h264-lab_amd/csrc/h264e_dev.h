@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #define H264E_MV_NA 0x8000
+#define H264E_ORDER_PAD 0xffffffffu     /* an entry of the dispatch order that is nobody's (padding of a banded order, h264e_pool.h build_order): the workgroup exits at once */
 #define H264E_MAX_SLICES 16             /* row-band slices per frame (== H264E_HIP_MAX_SLICES) */
 #define H264E_ROW_BYTES_PER_MB 2048     /* capacity of a row bit buffer, per macroblock of the row */
 

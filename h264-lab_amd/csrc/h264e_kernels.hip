@@ -148,6 +148,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
     /* workgroups are dispatched in index order: `order` lists (job, row) by the step at which the row can start
      * (H264E_FRAME_LAG*job + 2*row), so the resident workgroups are the ones that can make progress */
     const uint32_t jr = order[blockIdx.x];
+    if (jr == H264E_ORDER_PAD) return;        /* padding of a banded dispatch order (h264e_pool.h build_order) */
     const int job = (int)(jr >> 16), row = (int)(jr & 0xffffu);
     const h264e_frame_task_t &T = tasks[job];
     if (!T.active) return;
@@ -657,9 +658,10 @@ __global__ void h264e_ssd_kernel(const uint8_t *clip, size_t frame_bytes, int wi
 
 /* variant: 0 = intra frames only (one wave per row, 4 per SIMD), 1 = one wave per row, 2 = two waves per row (3 per SIMD), 3 = the latency variant: four
  * waves per row (search | reconstruction | 8x8 search helper | deblocking and stores), 4 = two waves per row at 4 per SIMD */
-static void bk_launch_mb(const h264e_geom_t &G, int narrow, int variant, unsigned nblocks, const h264e_frame_task_t *td, const uint32_t *od, hipStream_t st)
+static void bk_launch_mb(const h264e_geom_t &G, int narrow, int variant, int njobs, unsigned nblocks, const h264e_frame_task_t *td, const uint32_t *od, hipStream_t st)
 {
     const dim3 grid(nblocks);
+    (void)njobs;
     if (variant == 0) hipLaunchKernelGGL((h264e_mb_kernel<GEOM_INTRA, 1, H264E_WPEI>), grid, dim3(64), 0, st, G, td, od);
     else if (variant == 4)
     {

@@ -154,7 +154,8 @@ struct h264e_hip_pool
     unsigned long long *mb_counter;      /* device: macroblocks reconstructed by this pool's rows, delivered or not (h264e_hip_mb_counter) */
     uint32_t *order;                     /* device [nchains*(nmby+1)] (job << 16) | row in dispatch order of the current launch shape */
     uint32_t *order_host;                /* host copy being built (build_order) */
-    int order_jobs, order_narrow;        /* the launch shape `order` holds: jobs, window geometry (-1: none yet) */
+    int order_jobs, order_narrow, order_sliced;   /* the launch shape `order` holds: jobs, window geometry, row-band slices or not (-1: none yet) */
+    size_t order_count;                  /* ... and its entries = the launch's workgroups (banded orders carry padding) */
     int *stepflags;                      /* [nchains][2]: {clusters_moved, overflow} of the last step, one read per step */
     /* streaming: per chain slot, host-mapped result buffers the finalizer workgroups fill while the launch runs */
     h264e_hostdone_t *host_done;         /* [nchains] */
@@ -262,14 +263,19 @@ extern "C" void h264e_hip_pool_destroy(h264e_hip_pool_t *p)
  * H264E_XCD_BANDS=N (experiment, profiles/r02_xcd_bands.txt): workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md:
  * blocks b and b+8 share one), so the order is additionally arranged so that a macroblock row lands on the XCD of its band of rows
  * (row*N/nmby mod 8): the rows whose reference windows overlap then share an L2. */
-static int build_order(h264e_hip_pool_t *p, int jobs, int narrow)
+/* entries a launch of `jobs` jobs can take in the dispatch order (banded: eight equally long queues per job, padded) */
+static size_t order_capacity(const h264e_geom_t &G, int jobs) { return (size_t)jobs*(size_t)(8*((G.nmby + 7)/8 + 1)); }
+static int build_order(h264e_hip_pool_t *p, int jobs, int narrow, int sliced)
 {
     const h264e_geom_t &G = p->G;
     const int rows = G.nmby + 1, total = jobs*rows, lag = narrow ? H264E_NARROW_FRAME_LAG : H264E_FRAME_LAG, maxkey = lag*(jobs - 1) + 2*(rows - 1);
-    /* measured with the two-wave kernel (gpurun_out/r3_bands1): 8 bands halve FETCH_SIZE everywhere (1080p: 1896 -> 919 MB per launch; fetch +
-     * write 2827 -> 1744 MB) -- and cost 2-4 % speed at 1080p and below, but GAIN 8 % at 4K, where a frame's rows no longer fit the L2s at
-     * random: on by default from 4K up */
-    const int bands = getenv("H264E_XCD_BANDS") ? atoi(getenv("H264E_XCD_BANDS")) : (G.nmb >= 30000 ? 8 : 0);
+    /* measured (gpurun_out/bands_pad, one MI355X, padded queues): 8 bands nearly halve FETCH_SIZE everywhere (1080p: 1521 -> 830 MB per
+     * launch, WRITE_SIZE 765 -> 603) -- HBM traffic nobody waits for at 2 % of the bandwidth -- and what they do to the SPEED depends on
+     * what a launch is short of: single-slice streams of big pictures gain (4K +5 %, 8K +14 %: a frame's rows no longer fit the L2s at
+     * random), everything else loses 1-13 % (1080p -4 %, 720p -1 %, CIF -13 %, rate control -4 %; row-band slices -9 % at every size,
+     * 4K and 8K included: a slice is a band, and an XCD cannot share its slice's load with the others).  So: on for single-slice
+     * launches from 4K up, H264E_XCD_BANDS=8 / 0 forces */
+    const int bands = getenv("H264E_XCD_BANDS") ? atoi(getenv("H264E_XCD_BANDS")) : (G.nmb >= 30000 && !sliced ? 8 : 0);
     uint32_t *ord = p->order_host;
     int *start = (int *)calloc((size_t)maxkey + 2, sizeof(int));
     uint32_t *tmp = bands ? (uint32_t *)malloc(sizeof(uint32_t)*(size_t)total) : ord;
@@ -278,36 +284,50 @@ static int build_order(h264e_hip_pool_t *p, int jobs, int narrow)
     for (int k = 0; k <= maxkey; k++) start[k + 1] += start[k];
     for (int job = 0; job < jobs; job++) for (int r = 0; r < rows; r++) tmp[start[lag*job + 2*r]++] = ((uint32_t)job << 16) | (uint32_t)r;     /* ties: by job */
     free(start);
+    p->order_count = (size_t)total;
     if (bands)
     {
-        /* eight queues in key order, one per XCD; slot i takes the head of queue i % 8 (or, when that one has run dry, the head with
-         * the smallest key) */
-        int head[8], cnt[8] = { 0 }, n = 0;
-        uint32_t *q = (uint32_t *)malloc(sizeof(uint32_t)*8*(size_t)total);
-        if (!q) { free(tmp); return -1; }
+        /* Eight queues in key order, one per XCD; slot i takes entry i / 8 of queue i % 8.  The queues are EQUALLY LONG, job by job:
+         * a band that has fewer rows than the tallest one (nmby is rarely a multiple of 8; one band also carries the finalizer) is
+         * padded with entries that are nobody's.  Without that the queues drift apart by a row or two per job, and because workgroups
+         * are dispatched strictly in index order, an XCD whose resident workgroups all wait for rows of a queue that lags behind
+         * blocks the dispatch of exactly those rows: measured as 2-4 % at 1080p with fixed bands, and as a dead launch ("bounded spin
+         * expired") once a launch is long enough -- 600 jobs of 720p, CIF, or 1080p with 8 slices. */
+        const int per = (G.nmby + 7)/8 + 1;
+        const size_t qlen = (size_t)per*jobs;
+        uint32_t *q = (uint32_t *)malloc(sizeof(uint32_t)*8*qlen);
+        int *fill = (int *)calloc((size_t)8*jobs, sizeof(int));
+        size_t cnt[8] = { 0 };
+        if (!q || !fill) { free(q); free(fill); free(tmp); return -1; }
+        for (size_t i = 0; i < 8*qlen; i++) q[i] = H264E_ORDER_PAD;
+        /* queue x, job j owns the entries [j*per, (j+1)*per) ... in KEY order that would interleave the jobs; so: append in key order, and
+         * when a job's last entry of a queue has gone in, append its padding right behind it */
+        int *want = (int *)calloc((size_t)8*jobs, sizeof(int));
+        if (!want) { free(q); free(fill); free(tmp); return -1; }
         for (int i = 0; i < total; i++)
         {
             const int row = (int)(tmp[i] & 0xffffu), x = (row >= G.nmby ? bands - 1 : imin_h(bands - 1, row*bands/G.nmby)) & 7;      /* band b -> XCD b % 8 */
-            q[(size_t)x*total + cnt[x]++] = tmp[i];
+            want[8*(tmp[i] >> 16) + x]++;
         }
-        for (int x = 0; x < 8; x++) head[x] = 0;
+        int empty = 0;
+        for (int i = 0; i < 8*jobs; i++) if (!want[i]) empty = 1;
+        if (empty)
+        {
+            /* fewer bands than XCDs (tiny pictures, H264E_XCD_BANDS < 8): no banding */
+            memcpy(ord, tmp, sizeof(uint32_t)*(size_t)total);
+            free(q); free(fill); free(want); free(tmp);
+            return 0;
+        }
         for (int i = 0; i < total; i++)
         {
-            int x = i & 7;
-            if (head[x] >= cnt[x])
-            {
-                long best = -1; x = -1;
-                for (int y = 0; y < 8; y++)
-                    if (head[y] < cnt[y])
-                    {
-                        const uint32_t jr2 = q[(size_t)y*total + head[y]];
-                        const long key = (long)lag*(long)(jr2 >> 16) + 2*(long)(jr2 & 0xffffu);
-                        if (x < 0 || key < best) { best = key; x = y; }
-                    }
-            }
-            ord[n++] = q[(size_t)x*total + head[x]++];
+            const int row = (int)(tmp[i] & 0xffffu), jb = (int)(tmp[i] >> 16), x = (row >= G.nmby ? bands - 1 : imin_h(bands - 1, row*bands/G.nmby)) & 7;
+            q[(size_t)x*qlen + cnt[x]++] = tmp[i];
+            if (++fill[8*jb + x] == want[8*jb + x]) cnt[x] += (size_t)(per - want[8*jb + x]);        /* the padding stays H264E_ORDER_PAD */
         }
-        free(q); free(tmp);
+        size_t n = 0;
+        for (size_t k = 0; k < qlen; k++) for (int x = 0; x < 8; x++) ord[n++] = q[(size_t)x*qlen + k];
+        p->order_count = n;
+        free(q); free(fill); free(want); free(tmp);
     }
     return 0;
 }
@@ -396,7 +416,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         p->abort_dev = (int *)carve(64, 256);
         p->walkrec = (h264e_walkrec_t *)carve(sizeof(h264e_walkrec_t)*(size_t)nchains, 256);
         p->ssd_dev = (unsigned long long *)carve(sizeof(unsigned long long)*3*(size_t)nchains, 256);
-        p->order = (uint32_t *)carve(sizeof(uint32_t)*(size_t)nchains*(G.nmby + 1), 256);
+        p->order = (uint32_t *)carve(sizeof(uint32_t)*order_capacity(G, nchains), 256);
         p->host_done = (h264e_hostdone_t *)hcarve(sizeof(h264e_hostdone_t)*(size_t)nchains);
         p->abort_word = (int *)hcarve(64);
         for (int c = 0; c < nchains; c++)
@@ -449,7 +469,7 @@ extern "C" int h264e_hip_pool_create(h264e_hip_pool_t **pool, int device, int wi
         h264e_hip_pool_destroy(p);
         FAIL("descriptor upload failed");
     }
-    p->order_host = (uint32_t *)malloc(sizeof(uint32_t)*(size_t)nchains*(G.nmby + 1));
+    p->order_host = (uint32_t *)malloc(sizeof(uint32_t)*order_capacity(G, nchains));
     if (!p->order_host) { h264e_hip_pool_destroy(p); FAIL("out of host memory"); }
     p->order_jobs = -1;
     *pool = p;
@@ -746,7 +766,7 @@ static int group_launch_locked(h264e_hip_group_t *g)
         if (!rc)
         {
             (void)hipEventRecord(g->ev_t0[narrow], g->stream);
-            bk_launch_mb(G, narrow, variant, (unsigned)total, td, od, g->stream);
+            bk_launch_mb(G, narrow, variant, jobs, (unsigned)total, td, od, g->stream);
             (void)hipEventRecord(g->ev_t1[narrow], g->stream);
             const hipError_t le = hipGetLastError();
             if (le != hipSuccess) GFAIL("group launch: %s", hipGetErrorString(le));
@@ -1026,15 +1046,15 @@ extern "C" int h264e_hip_submit(h264e_hip_pool_t *p, const h264e_hip_task_t *tas
     }
     free(host);
     /* the dispatch order for this launch's shape (jobs up to the last active one; window geometry) */
-    if (njobs != p->order_jobs || any_narrow != p->order_narrow)
+    if (njobs != p->order_jobs || any_narrow != p->order_narrow || (max_slices >= 2) != p->order_sliced)
     {
-        if (build_order(p, njobs, any_narrow)) FAIL("out of host memory");
-        HIPCHK(hipMemcpyAsync(p->order, p->order_host, sizeof(uint32_t)*(size_t)njobs*(G.nmby + 1), hipMemcpyHostToDevice, p->stream));     /* pageable: staged before the call returns */
-        p->order_jobs = njobs; p->order_narrow = any_narrow;
+        if (build_order(p, njobs, any_narrow, max_slices >= 2)) FAIL("out of host memory");
+        HIPCHK(hipMemcpyAsync(p->order, p->order_host, sizeof(uint32_t)*p->order_count, hipMemcpyHostToDevice, p->stream));     /* pageable: staged before the call returns */
+        p->order_jobs = njobs; p->order_narrow = any_narrow; p->order_sliced = max_slices >= 2;
     }
     const int pe = p->ev_pending;
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][0], p->stream));
-    bk_launch_mb(G, any_narrow, waves, (unsigned)(njobs*(G.nmby + 1)), slot, p->order, p->stream);
+    bk_launch_mb(G, any_narrow, waves, njobs, (unsigned)p->order_count, slot, p->order, p->stream);
     if (p->profile) HIPCHK(hipEventRecord(p->ev[pe][1], p->stream));
     HIPCHK(hipGetLastError());
     if (p->profile)

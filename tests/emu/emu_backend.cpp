@@ -48,10 +48,9 @@ extern "C" void emu_check_global(const void *p, size_t n, const char *file, int 
 #include "../../include/h264e_hip.h"
 
 /* variant 0 = a launch of intra frames only (the kernel variant without inter code), like h264e_kernels.hip bk_launch_mb */
-static void bk_launch_mb(const h264e_geom_t &G, int narrow, int variant, unsigned nblocks, const h264e_frame_task_t *tasks, const uint32_t *order, hipStream_t)
+static void bk_launch_mb(const h264e_geom_t &G, int narrow, int variant, int njobs, unsigned nblocks, const h264e_frame_task_t *tasks, const uint32_t *order, hipStream_t)
 {
-    const int njobs = (int)(nblocks/(unsigned)(G.nmby + 1));
-    (void)order;
+    (void)order; (void)nblocks;
     for (int job = 0; job < njobs; job++)
     {
         const h264e_frame_task_t &T = tasks[job];
