@@ -1263,6 +1263,23 @@ extern "C" int h264e_hip_rewind_frame(h264e_hip_pool_t *p, int chain, int slot)
     return 0;
 }
 
+/* test hook: the dispatch order build_order makes for a launch of `jobs` jobs (banded = 1 forces the XCD bands with their padding, 0 none);
+ * returns the number of entries (out gets at most cap of them), -1 on failure.  Leaves the pool's cached order invalid. */
+extern "C" long h264e_hip_selftest_order(h264e_hip_pool_t *p, int jobs, int narrow, int banded, uint32_t *out, size_t cap)
+{
+    if (!p || jobs < 1 || jobs > p->nchains || !out) { snprintf(g_err, sizeof(g_err), "selftest_order: bad argument"); return -1; }
+    const char *old = getenv("H264E_XCD_BANDS");
+    char keep[32];
+    if (old) snprintf(keep, sizeof(keep), "%s", old);
+    setenv("H264E_XCD_BANDS", banded ? "8" : "0", 1);
+    const int rc = build_order(p, jobs, narrow, 0);
+    if (old) setenv("H264E_XCD_BANDS", keep, 1); else unsetenv("H264E_XCD_BANDS");
+    p->order_jobs = -1;
+    if (rc) { snprintf(g_err, sizeof(g_err), "out of host memory"); return -1; }
+    memcpy(out, p->order_host, sizeof(uint32_t)*(p->order_count < cap ? p->order_count : cap));
+    return (long)p->order_count;
+}
+
 extern "C" int h264e_hip_selftest_nal_escape(h264e_hip_pool_t *p, const uint8_t *src, uint32_t n, uint8_t *dst, uint32_t cap, uint32_t *out_n)
 {
     if (!p || !src || !dst || !out_n) FAIL("selftest_nal_escape: bad argument");

@@ -172,6 +172,9 @@ int  h264e_hip_timer_stop(h264e_hip_pool_t *pool, double *ms);
 /* self-test hook: runs the device's NAL emulation-prevention pass (enc_row.h nal_escape_copy, one wavefront) on n payload bytes;
  * dst receives start code + escaped payload, *out_n its size.  Used by tests with adversarial inputs (real streams need an
  * escape about once per 4 MB). */
+/* test hook: the dispatch order of a launch of `jobs` jobs as (job << 16 | row) entries, 0xffffffff = padding (banded orders: eight
+ * equally long per-XCD queues, h264e_pool.h build_order); returns the number of entries, -1 on failure */
+long h264e_hip_selftest_order(h264e_hip_pool_t *pool, int jobs, int narrow, int banded, uint32_t *out, size_t cap);
 int  h264e_hip_selftest_nal_escape(h264e_hip_pool_t *pool, const uint8_t *src, uint32_t n, uint8_t *dst, uint32_t cap, uint32_t *out_n);
 /* test hook: one wave-level stage of the macroblock pipeline on caller-supplied operands (h264e_kernels.hip stage_selftest lists
  * the stages and their operand layouts; tests/test_stages.py compares them with the reference's own functions) */

@@ -378,3 +378,48 @@ def test_set_vbv_state_mid_stream_matches_reference(name):
     e = pkg.load_pkg().Encoder(g["w"], g["h"], gop=g["gop"], kbps=g["kbps"], lib=pkg.EMU_LIB)
     _run_vbv_case(e, g)
     e.close()
+
+
+@pytest.mark.parametrize("w,h,jobs,narrow", [(1920, 1088, 37, 1), (3840, 2160, 9, 0), (352, 288, 50, 1), (640, 368, 20, 1)])
+def test_dispatch_order_with_xcd_bands_is_complete_padded_and_dependency_safe(w, h, jobs, narrow):
+    """h264e_pool.h build_order (the product's code, through the emulation library): with XCD bands the order is eight per-XCD queues
+    dealt round -- slot i belongs to XCD i % 8.  Every (job, row) is there exactly once; a row sits on the XCD of its band; the queues
+    are equally long job by job (padding), so no XCD runs ahead of another by more than a job's worth of rows; and inside one XCD's
+    queue the start keys never decrease -- a workgroup waits only for workgroups in front of it or on other XCDs."""
+    import ctypes as C
+    P = pkg.load_pkg()
+    L = P.load(pkg.EMU_LIB)
+    L.h264e_hip_pool_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.h264e_hip_pool_destroy.argtypes = [C.c_void_p]
+    L.h264e_hip_selftest_order.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_size_t]
+    L.h264e_hip_selftest_order.restype = C.c_long
+    pool = C.c_void_p()
+    assert L.h264e_hip_pool_create(C.byref(pool), 0, w, h, jobs, 1, 1) == 0
+    try:
+        nmby, lag = (h + 15) // 16, 4 if narrow else 7
+        rows = nmby + 1
+        cap = jobs * (rows + 16)
+        buf = (C.c_uint32 * cap)()
+        plain = L.h264e_hip_selftest_order(pool, jobs, narrow, 0, buf, cap)
+        assert plain == jobs * rows
+        assert sorted(buf[:plain]) == sorted((j << 16) | r for j in range(jobs) for r in range(rows))
+        n = L.h264e_hip_selftest_order(pool, jobs, narrow, 1, buf, cap)
+        assert 0 < n <= cap and n % 8 == 0
+        order = list(buf[:n])
+        real = [e for e in order if e != 0xffffffff]
+        assert sorted(real) == sorted((j << 16) | r for j in range(jobs) for r in range(rows))
+        per = (nmby + 7) // 8 + 1
+        assert n == 8 * per * jobs                       # equally long queues, job by job
+        for x in range(8):
+            q = order[x::8]
+            keys = [lag * (e >> 16) + 2 * (e & 0xffff) for e in q if e != 0xffffffff]
+            assert keys == sorted(keys)
+            for e in q:
+                if e != 0xffffffff and (e & 0xffff) < nmby:
+                    assert min(7, (e & 0xffff) * 8 // nmby) == x
+            # entry k of every queue belongs to a job within one of k // per: the queues advance together
+            for k, e in enumerate(q):
+                if e != 0xffffffff:
+                    assert abs((e >> 16) - k // per) <= (2 * rows) // lag + 1
+    finally:
+        L.h264e_hip_pool_destroy(pool)
