@@ -30,6 +30,10 @@
 
 /* relaxed poll of one progress counter until it reaches `need`.  Returns 0 = reached, -1 = producer failed or the
  * bound expired, -2 = producer was aborted (negative counters are poison left behind by a row that stopped). */
+#ifndef H264E_POLL_SLEEP
+#define H264E_POLL_SLEEP 8          /* x 64 cycles between two polls of a counter in device memory (1, 2, 8, 16 measured in round 4: level within 0.3 %
+                                       -- stream, 8 slices, rate control, lone frame: the round trip of the poll itself is what a hand-off costs) */
+#endif
 DEV int poll_progress(const GLOBAL_AS int *flag, int need, int &seen, unsigned spin_limit)
 {
     unsigned spins = 0;
@@ -39,7 +43,7 @@ DEV int poll_progress(const GLOBAL_AS int *flag, int need, int &seen, unsigned s
         if (seen >= need) return 0;
         if (seen < 0) return seen;
         if (++spins > spin_limit) return -1;
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(H264E_POLL_SLEEP);
     }
 }
 
