@@ -31,8 +31,11 @@
 /* relaxed poll of one progress counter until it reaches `need`.  Returns 0 = reached, -1 = producer failed or the
  * bound expired, -2 = producer was aborted (negative counters are poison left behind by a row that stopped). */
 #ifndef H264E_POLL_SLEEP
-#define H264E_POLL_SLEEP 8          /* x 64 cycles between two polls of a counter in device memory (1, 2, 8, 16 measured in round 4: level within 0.3 %
-                                       -- stream, 8 slices, rate control, lone frame: the round trip of the poll itself is what a hand-off costs) */
+/* x 64 cycles between two polls of a counter in device memory.  Measured in round 4 (gpurun_out/sleep_ab, sleep2): 1, 2, 8, 16, 32 are level
+ * within 0.3 % in every regime (stream, 8 slices, rate control, lone frame: the round trip of the poll itself is what a hand-off costs);
+ * what changes is what the parked waves issue meanwhile: with 16 here and 4 for the LDS hand-off words below, the scalar instructions
+ * per delivered macroblock go from 10.6 k to 9.2 k (LDS 1.86 k -> 1.66 k) at the same speed */
+#define H264E_POLL_SLEEP 16
 #endif
 DEV int poll_progress(const GLOBAL_AS int *flag, int need, int &seen, unsigned spin_limit)
 {
@@ -55,6 +58,9 @@ DEV void publish(GLOBAL_AS int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RE
 /* ---- hand-off words of the two-wave pipeline (LDS): release / acquire at workgroup scope, polled with s_sleep */
 DEV int flag_get(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DEV void flag_set(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#ifndef H264E_LDS_SLEEP
+#define H264E_LDS_SLEEP 4            /* x 64 cycles between two looks at a hand-off word in LDS (1, 2, 4 measured level, see H264E_POLL_SLEEP) */
+#endif
 #define LDS_SPIN_LIMIT (1u << 26)       /* the partner wave is resident: this bound only ever ends a wait when something is badly wrong */
 /* 0 = *flag reached need; otherwise the stop code the partner wave (or this bound) left: -1 failure, -2 abort */
 DEV int lds_wait(const int *flag, int need, int *stop)
@@ -65,7 +71,7 @@ DEV int lds_wait(const int *flag, int need, int *stop)
         const int s = uni(flag_get(stop));
         if (s) return s;
         if (spins > LDS_SPIN_LIMIT) { flag_set(stop, -1); return -1; }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(H264E_LDS_SLEEP);
     }
 }
 /* what the search wave tells the reconstruction wave while it is still searching macroblock need - 1 (enc_mb.h inter_choose) */
@@ -103,7 +109,7 @@ struct InterFromSearchWave
             if (uni(flag_get(&L->f_inter)) >= need || uni(flag_get(f)) >= need) return true;
             if (uni(flag_get(&L->f_stop))) return false;
             if (spins > LDS_SPIN_LIMIT) { flag_set(&L->f_stop, -1); return false; }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(H264E_LDS_SLEEP);
         }
     }
     DEVM bool wait_noskip_or_ready() const { return wait_either(&L->f_noskip); }
@@ -248,7 +254,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
                 if (spins > G.spin_limit) return -1;
                 /* waiting for row r: the rows above it are complete (and acquired) -- is their walk due? */
                 if (r > 0 && walk_upto(r - 1)) return 1;
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(H264E_POLL_SLEEP);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -495,7 +501,7 @@ __global__ void __launch_bounds__(64*WAVES, OCC) h264e_mb_kernel(h264e_geom_t G,
                 if (uni(flag_get(&L.f_inter)) >= x + 1) break;                      /* the search wave is done with x without asking */
                 if (uni(flag_get(&L.f_stop))) { st = 1; break; }
                 if (spins > LDS_SPIN_LIMIT) { flag_set(&L.f_stop, -1); st = 1; break; }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(H264E_LDS_SLEEP);
             }
             if (st) return;
             if (!req) continue;
