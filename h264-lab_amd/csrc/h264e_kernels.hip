@@ -119,9 +119,10 @@ struct InterFromSearchWave
 /*
  * Grid: njobs x (nmby + 1) workgroups of one wavefront -- or of two (WAVES = 2): the macroblock loop as a two-stage pipeline, one
  * wavefront searching macroblock x + 1 while the other reconstructs and writes x (enc_row.h).  Workgroup `row < nmby` encodes macroblock row
- * `row` of its job's frame; workgroup `nmby` is the job's finalizer: once every row has ended it splices the slice
- * (finalize_frame) and, in streaming use, exports the result to host-mapped memory and raises the job's done word,
- * so the host consumes frames while later frames of the same launch are still being encoded.
+ * `row` of its job's frame; workgroup `nmby` is the job's finalizer: it follows the frame's rows as they end -- splices each into the
+ * slice (enc_row.h splice_frame), walks its records (exact mv_clusters validation, JobWalk) -- and, in streaming use, exports the result
+ * to host-mapped memory and raises the job's done word, so the host consumes frames while later frames of the same launch are still
+ * being encoded.  Padding entries of a banded dispatch order (H264E_ORDER_PAD) are workgroups that exit at once.
  * Every workgroup waits for workgroups with a lower index (rows above; rows of the reference frame's job inside the
  * static lag; rows of the own job for the finalizer) -- with ONE exception: a reference read that leaves the LDS window
  * (a long vector) waits dynamically for the exact rows it touches, which can lie a bounded distance AHEAD in the dispatch
