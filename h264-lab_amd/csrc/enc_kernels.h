@@ -459,8 +459,8 @@ DEV int tap6(int a, int b, int c, int d, int e, int f) { return a - 5*b + 20*c +
  * operands it finds 24-bit multiply-adds with byte selects by itself: measured, the shift form is slower there) */
 DEV int tap6w(int a, int b, int c, int d, int e, int f)
 {
-    const int t = ((c + d) << 2) - (b + e);
-    return (a + f) + (t << 2) + t;
+    const int t = (c + d)*4 - (b + e);           /* (x*4: a shift / shift-add for the compiler, and defined for negative x) */
+    return (a + f) + t*4 + t;
 }
 
 /*
